@@ -1,0 +1,109 @@
+"""In-tree builds of the native pieces (no JIT cache, no pip install).
+
+  build_hip()    hipcc --offload-arch=gfx950  -> epievo_amd/libepievo_mi355x.so
+                 (the C-ABI of include/epievo_mi355x.h: HIP kernels + host glue)
+  build_host()   g++                          -> epievo_amd/libepv_host.so
+                 (model / M-step / file formats / synthetic-input simulator)
+  build_cli()    g++                          -> epievo_amd/bin/epievo_*  (drop-in CLIs)
+  build_oracle() make -C oracle [ref]         -> oracle/liborc.so (+ oracle/_ref/…)
+                 TEST INFRASTRUCTURE ONLY; the product never loads it.
+"""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(CSRC, "host")
+INCLUDE = os.path.join(ROOT, "include")
+
+HIP_SO = os.path.join(PKG, "libepievo_mi355x.so")
+HOST_SO = os.path.join(PKG, "libepv_host.so")
+BIN_DIR = os.path.join(PKG, "bin")
+
+HOST_SOURCES = ["epv_model.cpp", "epv_sim.cpp", "epv_io.cpp", "epv_host_abi.cpp"]
+# the reference library is built -O3 without -march (no FMA contraction); match it
+HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _run(cmd, **kw):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def hipcc_path():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build_hip(force=False):
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
+            if f.endswith((".hip", ".h", ".hpp"))]
+    srcs.append(os.path.join(INCLUDE, "epievo_mi355x.h"))
+    if not force and _newer(HIP_SO, srcs):
+        return HIP_SO
+    units = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           # bit-parity with the CPU oracle: no implicit FMA contraction, IEEE div/sqrt
+           "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+           "-I", INCLUDE, "-I", CSRC, "-o", HIP_SO] + units
+    _run(cmd)
+    return HIP_SO
+
+
+def build_host(force=False):
+    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".cpp", ".hpp"))]
+    if not force and _newer(HOST_SO, srcs):
+        return HOST_SO
+    cmd = ["g++"] + HOST_FLAGS + ["-shared", "-I", HOST, "-I", INCLUDE, "-o", HOST_SO] + \
+        [os.path.join(HOST, f) for f in HOST_SOURCES]
+    _run(cmd)
+    return HOST_SO
+
+
+def build_oracle(with_ref=True):
+    odir = os.path.join(ROOT, "oracle")
+    _run(["make", "-C", odir])
+    if with_ref and os.path.isdir("/root/reference/src/libepievo"):
+        _run(["make", "-C", odir, "-j8", "ref"])
+    return os.path.join(odir, "liborc.so")
+
+
+def build_all(force=False):
+    build_host(force)
+    build_hip(force)
+    cli = os.path.join(HOST, "cli")
+    if os.path.isdir(cli):
+        build_cli(force)
+    build_oracle()
+
+
+def build_cli(force=False):
+    cli = os.path.join(HOST, "cli")
+    os.makedirs(BIN_DIR, exist_ok=True)
+    common = [os.path.join(HOST, f) for f in ("epv_model.cpp", "epv_sim.cpp", "epv_io.cpp",
+                                              "epv_sampler.cpp", "epv_options.cpp")]
+    outs = []
+    for f in sorted(os.listdir(cli)):
+        if not f.endswith(".cpp"):
+            continue
+        out = os.path.join(BIN_DIR, f[:-4])
+        srcs = [os.path.join(cli, f)] + common
+        if force or not _newer(out, srcs + [HIP_SO]):
+            _run(["g++"] + [x for x in HOST_FLAGS if x not in ("-fPIC", "-fvisibility=hidden")] +
+                 ["-I", HOST, "-I", INCLUDE, "-o", out] + srcs +
+                 ["-L", PKG, "-lepievo_mi355x", "-Wl,-rpath,$ORIGIN/.."])
+        outs.append(out)
+    return outs

@@ -1,0 +1,145 @@
+// epv_host_abi.cpp -- flat C face of the host-side library (libepv_host.so) so that
+// Python tests / bench.py can drive the same C++ host code the CLI programs use.
+// No GPU code here; no exceptions cross the boundary (non-zero return = failure,
+// message via epvh_last_error).
+#include <cstring>
+#include <string>
+
+#include "epv_model.hpp"
+#include "epv_sim.hpp"
+#include "epv_io.hpp"
+
+namespace {
+thread_local std::string g_err;
+void put_model(const epv::Model &m, double *rates, double *T, double *baseline) {
+  for (int i = 0; i < 8; ++i) rates[i] = m.rates[i];
+  for (int i = 0; i < 4; ++i) { T[i] = m.T[i]; baseline[i] = m.baseline[i]; }
+}
+void put_text(const std::string &s, char *buf, int len) {
+  if (!buf || len <= 0) return;
+  std::strncpy(buf, s.c_str(), (size_t)len - 1);
+  buf[len - 1] = '\0';
+}
+}  // namespace
+
+#define EPVH_API extern "C" __attribute__((visibility("default")))
+
+EPVH_API const char *epvh_last_error() { return g_err.c_str(); }
+
+// read_model (+ optional scale_triplet_rates), est_params_histories.cpp:169-171
+EPVH_API int epvh_model_read(const char *param_file, int scale, double *rates, double *T,
+                             double *baseline) {
+  try {
+    epv::Model m = epv::Model::read(param_file);
+    if (scale) m.scale_triplet_rates();
+    put_model(m, rates, T, baseline);
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+EPVH_API double epvh_rate_scaling_factor(const double *rates) {
+  std::array<double, 8> r;
+  for (int i = 0; i < 8; ++i) r[i] = rates[i];
+  return epv::rate_scaling_factor(r);
+}
+
+// the M-step exactly as the EM driver sequences it (est_params_histories.cpp:253-263).
+// rates/branches are in-out; T, baseline, param_text are outputs; returns 0 / non-zero.
+EPVH_API int epvh_m_step(int optimize_branches, int n_nodes, const double *J, const double *D,
+                         double *rates, double *T, double *baseline, double *branches,
+                         double *llh, char *param_text, int param_text_len) {
+  try {
+    epv::Model m;
+    std::array<double, 8> r;
+    for (int i = 0; i < 8; ++i) r[i] = rates[i];
+    m.rebuild_from_triplet_rates(r);
+    std::vector<double> br(branches, branches + n_nodes);
+    if (!optimize_branches) {
+      *llh = epv::estimate_rates(1e-10, n_nodes, J, D, m);
+      epv::set_one_change_per_site_per_unit_time(m.rates, br);
+    } else {
+      *llh = epv::estimate_rates_and_branches(1e-10, n_nodes, J, D, br, m);
+    }
+    put_model(m, rates, T, baseline);
+    for (int b = 0; b < n_nodes; ++b) branches[b] = br[b];
+    put_text(m.format_for_param_file(), param_text, param_text_len);
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// ---- forward simulation of synthetic histories
+EPVH_API void *epvh_simulate(const double *rates, const double *T, int n_nodes,
+                             const uint32_t *parent, const double *branches,
+                             uint64_t n_sites, uint64_t seed) {
+  try {
+    epv::Model m;
+    for (int i = 0; i < 8; ++i) m.rates[i] = rates[i];
+    for (int i = 0; i < 4; ++i) m.T[i] = T[i];
+    epv::FlatPaths *fp = new epv::FlatPaths(
+        epv::simulate_histories(m, n_nodes, parent, branches, n_sites, seed));
+    return fp;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+EPVH_API uint64_t epvh_paths_total_jumps(void *h) {
+  return static_cast<epv::FlatPaths *>(h)->jumps.size();
+}
+EPVH_API uint64_t epvh_paths_n_sites(void *h) { return static_cast<epv::FlatPaths *>(h)->n_sites; }
+EPVH_API int epvh_paths_n_nodes(void *h) { return static_cast<epv::FlatPaths *>(h)->n_nodes; }
+EPVH_API void epvh_paths_copy(void *h, uint8_t *init, uint64_t *offsets, double *jumps) {
+  const epv::FlatPaths *fp = static_cast<epv::FlatPaths *>(h);
+  std::memcpy(init, fp->init.data(), fp->init.size());
+  std::memcpy(offsets, fp->offsets.data(), fp->offsets.size() * sizeof(uint64_t));
+  if (!fp->jumps.empty())
+    std::memcpy(jumps, fp->jumps.data(), fp->jumps.size() * sizeof(double));
+}
+EPVH_API void epvh_paths_free(void *h) { delete static_cast<epv::FlatPaths *>(h); }
+
+// ---- file formats (local_paths, Newick tree)
+EPVH_API void *epvh_read_paths(const char *path_file, char *names_buf, int names_len,
+                               double *tot_times, int max_nodes) {
+  try {
+    std::vector<std::string> names;
+    std::vector<double> tt;
+    epv::FlatPaths *fp = new epv::FlatPaths(epv::read_local_paths(path_file, names, tt));
+    std::string joined;
+    for (size_t i = 0; i < names.size(); ++i) joined += (i ? "\n" : "") + names[i];
+    put_text(joined, names_buf, names_len);
+    for (int b = 0; b < fp->n_nodes && b < max_nodes; ++b) tot_times[b] = tt[b];
+    return fp;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+
+EPVH_API int epvh_write_paths(const char *path_file, const char *names_joined, int n_nodes,
+                              uint64_t n_sites, const double *tot_times, const uint8_t *init,
+                              const uint64_t *offsets, const double *jumps) {
+  try {
+    std::vector<std::string> names;
+    std::string cur;
+    for (const char *p = names_joined;; ++p) {
+      if (*p == '\n' || *p == '\0') { names.push_back(cur); cur.clear(); if (!*p) break; }
+      else cur.push_back(*p);
+    }
+    epv::write_local_paths(path_file, names, n_nodes, n_sites, tot_times, init, offsets, jumps);
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// parse a Newick file into pre-order arrays; returns n_nodes (<= max_nodes) or -1
+EPVH_API int epvh_read_tree(const char *tree_file, int max_nodes, uint32_t *subtree,
+                            uint32_t *parent, double *branches, char *names_buf,
+                            int names_len) {
+  try {
+    epv::Tree t = epv::Tree::read(tree_file);
+    const int n = (int)t.subtree_sizes.size();
+    if (n > max_nodes) { g_err = "tree too large"; return -1; }
+    std::string joined;
+    for (int i = 0; i < n; ++i) {
+      subtree[i] = t.subtree_sizes[i];
+      parent[i] = t.parent_ids[i];
+      branches[i] = t.branches[i];
+      joined += (i ? "\n" : "") + t.node_names[i];
+    }
+    put_text(joined, names_buf, names_len);
+    return n;
+  } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}

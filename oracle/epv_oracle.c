@@ -1,0 +1,697 @@
+/* epv_oracle.c -- TEST INFRASTRUCTURE: CPU restatement of epievo's MCEM inner
+ * loop (the per-site Metropolis-Hastings end-conditioned path sampler).
+ *
+ * This file is the parity oracle for the MI355X build.  It is NOT part of the
+ * product path: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  It restates, in plain C over flat arrays,
+ * what these reference functions compute (file:line under /root/reference):
+ *
+ *   collect_segment_info              src/libepievo/Segment.cpp:35-79
+ *   continuous_time_trans_prob_mat    src/libepievo/ContinuousTimeMarkovModel.cpp:143-161
+ *   TwoStateCTMarkovModel::get_trans_prob             ...:116-125
+ *   pruning / pruning_branch / process_branch_above   src/libepievo/SingleSiteSampler.cpp:80-157
+ *   downward_sampling(_branch)                        ...:180-255
+ *   forward_sampling / end_cond_sample_forward_rejection  src/libepievo/EndCondSampling.cpp:466-509
+ *   proposal_prob(_branch)                            SingleSiteSampler.cpp:272-339
+ *   path_log_likelihood / root_prior_lh / log_likelihood  ...:263-269,342-391
+ *   add_sufficient_statistics                         src/libepievo/Path.cpp:206-301
+ *   log_accept_rate                                   SingleSiteSampler.cpp:396-433
+ *   Metropolis_Hastings_site / single_iteration / reset / run_mcmc  ...:449-598
+ *   get_sufficient_statistics (per branch)            src/libepievo/ParamEstimation.cpp:92-114
+ *   scale_jump_times                                  ...:369-380
+ *
+ * Two modes (the "oracle ladder" of SURVEY.md section 8c):
+ *   rung A  reference-schedule: sequential sweep, mt19937 + libstdc++
+ *           distribution semantics, glibc exp/log, sequential J/D sums.
+ *           Pinned bit-for-bit against the linked reference (oracle/_ref) and
+ *           the golden fixtures in tests/golden/.
+ *   rung B  parallel-schedule: 3-colour sweep, random-access Philox4x32-10,
+ *           orc_exp/orc_log, canonical binary-tree J/D reduction, bounded
+ *           jump capacity.  This is the contract the gfx950 kernels match
+ *           bit-for-bit.
+ * Both rungs run the SAME per-site function below; only the random source,
+ * the exp/log pair, the visiting order and the reduction order differ.
+ *
+ * Path storage: node-major flat arrays, index (node*n_sites + site), node 0
+ * (the root) unused -- as in the reference, where paths[site][0] is a dummy.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdio.h>
+
+#include "orc_math.h"
+#include "orc_rng.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+enum { ORC_RNG_MT = 0, ORC_RNG_PHILOX = 1 };
+enum { ORC_MATH_LIBM = 0, ORC_MATH_EPV = 1 };
+enum { ORC_SCHED_SEQ = 0, ORC_SCHED_3COLOUR = 1 };
+enum { ORC_REDUCE_SEQ = 0, ORC_REDUCE_TREE = 1 };
+
+typedef struct {
+  uint8_t init;
+  uint32_t n, cap;
+  double *t;
+} orc_path;
+
+typedef struct {
+  int K, cap;
+  double *len;      /* segment length */
+  uint8_t *trip0;   /* context index with middle bit 0 (trip1 = trip0|2) */
+  double *p0, *p1;  /* Felsenstein partials at the top of each segment */
+} orc_segs;
+
+typedef struct {
+  orc_segs *segs;   /* [n_nodes] */
+  double *q0, *q1;  /* [n_nodes] */
+  orc_path *prop;   /* [n_nodes] proposed path */
+  double *trial;    /* jumps of the current rejection trial */
+  uint32_t trial_cap;
+} orc_scratch;
+
+typedef struct orc_state {
+  size_t n_sites;
+  int n_nodes;
+  uint32_t *parent, *subtree;
+  double *blen;
+  double rates[8], log_rates[8], T[4];
+  orc_path *paths;
+  double *tri_llh;
+  int rng_mode, math_mode, schedule, reduce_mode;
+  uint32_t cap; /* max jumps per (site,branch) path; 0 = unbounded */
+  orc_mt19937 mt;
+  uint64_t seed;
+  double (*fexp)(double);
+  double (*flog)(double);
+  orc_scratch scr;
+  /* counters */
+  uint64_t n_overflow, n_trials, n_draws, n_segments;
+} orc_state;
+
+static double libm_exp(double x) { return exp(x); }
+static double libm_log(double x) { return log(x); }
+static double epv_exp_(double x) { return orc_exp(x); }
+static double epv_log_(double x) { return orc_log(x); }
+
+/* ------------------------------------------------------------------ paths */
+static void path_reserve(orc_path *p, uint32_t need) {
+  if (need <= p->cap) return;
+  uint32_t c = p->cap ? p->cap * 2 : 4;
+  while (c < need) c *= 2;
+  p->t = (double *)realloc(p->t, (size_t)c * sizeof(double));
+  p->cap = c;
+}
+static void path_push(orc_path *p, double t) {
+  path_reserve(p, p->n + 1);
+  p->t[p->n++] = t;
+}
+static inline int path_end_state(const orc_path *p) { return p->init ^ (p->n & 1u); }
+static inline orc_path *PATH(const orc_state *st, int node, size_t site) {
+  return &st->paths[(size_t)node * st->n_sites + site];
+}
+
+static inline int is_leaf(const orc_state *st, int node) { return st->subtree[node] == 1; }
+
+/* ------------------------------------------------------------- segments */
+static void segs_reserve(orc_segs *s, int need) {
+  if (need <= s->cap) return;
+  int c = s->cap ? s->cap * 2 : 8;
+  while (c < need) c *= 2;
+  s->len = (double *)realloc(s->len, (size_t)c * sizeof(double));
+  s->trip0 = (uint8_t *)realloc(s->trip0, (size_t)c);
+  s->p0 = (double *)realloc(s->p0, (size_t)c * sizeof(double));
+  s->p1 = (double *)realloc(s->p1, (size_t)c * sizeof(double));
+  s->cap = c;
+}
+
+/* Segment.cpp:35-79: 2-way merge of the neighbours' jump lists; a left jump
+ * is taken only when strictly earlier than the right one. */
+static void collect_segments(const orc_path *l, const orc_path *r, double tot_time,
+                             orc_segs *s) {
+  segs_reserve(s, (int)(l->n + r->n + 1));
+  int K = 0;
+  uint8_t trip0 = (uint8_t)(4 * l->init + r->init);
+  double prev = 0.0;
+  uint32_t i = 0, j = 0;
+  while (i < l->n && j < r->n) {
+    if (l->t[i] < r->t[j]) {
+      s->len[K] = l->t[i] - prev; s->trip0[K] = trip0; ++K;
+      trip0 ^= 4; prev = l->t[i++];
+    } else {
+      s->len[K] = r->t[j] - prev; s->trip0[K] = trip0; ++K;
+      trip0 ^= 1; prev = r->t[j++];
+    }
+  }
+  for (; i < l->n; ++i) {
+    s->len[K] = l->t[i] - prev; s->trip0[K] = trip0; ++K;
+    trip0 ^= 4; prev = l->t[i];
+  }
+  for (; j < r->n; ++j) {
+    s->len[K] = r->t[j] - prev; s->trip0[K] = trip0; ++K;
+    trip0 ^= 1; prev = r->t[j];
+  }
+  s->len[K] = tot_time - prev; s->trip0[K] = trip0; ++K;
+  s->K = K;
+}
+
+/* --------------------------------------------------- 2-state CTMC pieces */
+/* ContinuousTimeMarkovModel.cpp:143-161 (h = 1.0/exp(.)) */
+static inline void trans_prob_mat(const orc_state *st, double r0, double r1, double t,
+                                  double P[4]) {
+  const double h = 1.0 / st->fexp(t * (r0 + r1));
+  const double denom = r0 + r1;
+  P[0] = (r0 * h + r1) / denom;
+  P[1] = 1.0 - P[0];
+  P[3] = (r0 + r1 * h) / denom;
+  P[2] = 1.0 - P[3];
+}
+/* ContinuousTimeMarkovModel.cpp:116-125 (h = exp(-.)) */
+static inline double get_trans_prob(const orc_state *st, double r0, double r1, double t,
+                                    int a, int b) {
+  const double h = st->fexp(-t * (r0 + r1));
+  const double denom = r0 + r1;
+  const double prob = (a ? r0 + r1 * h : r0 * h + r1) / denom;
+  return (a == b) ? prob : 1.0 - prob;
+}
+
+/* ------------------------------------------------------------- pruning */
+/* SingleSiteSampler.cpp:80-157 */
+static void pruning(const orc_state *st, size_t site, orc_scratch *sc) {
+  for (int node = st->n_nodes - 1; node >= 0; --node) {
+    double q0 = 1.0, q1 = 1.0;
+    if (is_leaf(st, node)) {
+      const int leaf_state = path_end_state(PATH(st, node, site));
+      q0 = leaf_state ? 0.0 : 1.0;
+      q1 = leaf_state ? 1.0 : 0.0;
+    } else {
+      /* children of `node` in pre-order: node+1, then skip subtrees */
+      for (uint32_t ch = 1; ch < st->subtree[node]; ch += st->subtree[node + ch]) {
+        const orc_segs *cs = &sc->segs[node + ch];
+        q0 *= cs->p0[0];
+        q1 *= cs->p1[0];
+      }
+    }
+    sc->q0[node] = q0;
+    sc->q1[node] = q1;
+    if (node == 0) continue;
+    orc_segs *s = &sc->segs[node];
+    double n0 = q0, n1 = q1;
+    for (int k = s->K - 1; k >= 0; --k) {
+      double P[4];
+      trans_prob_mat(st, st->rates[s->trip0[k]], st->rates[s->trip0[k] | 2], s->len[k], P);
+      const double a = P[0] * n0 + P[1] * n1;
+      const double b = P[2] * n0 + P[3] * n1;
+      s->p0[k] = a; s->p1[k] = b;
+      n0 = a; n1 = b;
+    }
+  }
+}
+
+/* ------------------------------------------------------ random sources */
+typedef struct {
+  orc_state *st;
+  uint32_t site, sweep;
+  uint32_t b, k, t, d;  /* current trial address and draw index */
+  double blk[2];
+} orc_rng;
+
+static inline double rng_segment_uniform(orc_rng *g, uint32_t b, uint32_t k) {
+  if (g->st->rng_mode == ORC_RNG_MT) return orc_mt_canonical(&g->st->mt);
+  double d[2];
+  orc_keyed_block(g->st->seed, g->site, g->sweep, b, k, 0, 0, d);
+  return d[0];
+}
+static inline double rng_accept_uniform(orc_rng *g) {
+  if (g->st->rng_mode == ORC_RNG_MT) return orc_mt_canonical(&g->st->mt);
+  double d[2];
+  orc_keyed_block(g->st->seed, g->site, g->sweep, 0, 0, 0, 0, d);
+  return d[0];
+}
+static inline void rng_trial_begin(orc_rng *g, uint32_t b, uint32_t k, uint32_t t) {
+  g->b = b; g->k = k; g->t = t; g->d = 0;
+}
+static inline double rng_trial_canonical(orc_rng *g) {
+  if (g->st->rng_mode == ORC_RNG_MT) return orc_mt_canonical(&g->st->mt);
+  if ((g->d & 1u) == 0)
+    orc_keyed_block(g->st->seed, g->site, g->sweep, g->b, g->k, g->t, g->d >> 1, g->blk);
+  return g->blk[g->d++ & 1u];
+}
+
+/* ------------------------------------------------ end-conditioned sampling */
+/* EndCondSampling.cpp:466-509.  Returns 0 ok, 1 capacity overflow.
+ * Appends accepted jump times (offset by start_time) to `out`. */
+static int forward_rejection(orc_state *st, orc_scratch *sc, orc_rng *g,
+                             uint32_t b, uint32_t k, double rate0, double rate1,
+                             int start, int end, double T, double start_time,
+                             orc_path *out) {
+  const uint32_t cap = st->cap;
+  const uint32_t room = cap ? cap - out->n : 0xffffffffu; /* jumps still storable */
+  uint32_t t = 1;
+  for (;;) {
+    rng_trial_begin(g, b, k, t);
+    uint32_t nj = 0;
+    int a = start;
+    double tau = 0.0;
+    int overflow = 0;
+    ++st->n_trials;
+    for (;;) {
+      const double u = rng_trial_canonical(g);
+      ++st->n_draws;
+      tau += -st->flog(1.0 - u) / (a ? rate1 : rate0);
+      if (!(tau < T)) break;
+      if (cap && nj >= room) { overflow = 1; break; }
+      a ^= 1;
+      if (nj >= sc->trial_cap) {
+        sc->trial_cap = sc->trial_cap ? sc->trial_cap * 2 : 16;
+        sc->trial = (double *)realloc(sc->trial, sc->trial_cap * sizeof(double));
+      }
+      sc->trial[nj++] = tau;
+    }
+    if (overflow) return 1;
+    if (a == end) {
+      for (uint32_t i = 0; i < nj; ++i) path_push(out, sc->trial[i] + start_time);
+      return 0;
+    }
+    ++t; /* the reference caps at 1e10 trials (EndCondSampling.cpp:52); unreachable */
+  }
+}
+
+/* SingleSiteSampler.cpp:180-255.  Returns 1 if the proposal overflowed. */
+static int downward_sampling(orc_state *st, size_t site, orc_scratch *sc, orc_rng *g,
+                             double *log_prob_out) {
+  double log_prob = 0.0;
+  int overflow = 0;
+  const int root_state = PATH(st, 1, site)->init; /* SAMPLE_ROOT == false (:246) */
+  sc->prop[0].init = (uint8_t)root_state;
+  sc->prop[0].n = 0;
+  for (int node = 1; node < st->n_nodes; ++node) {
+    orc_path *pp = &sc->prop[node];
+    const int start_state = path_end_state(&sc->prop[st->parent[node]]);
+    pp->init = (uint8_t)start_state;
+    pp->n = 0;
+    const orc_segs *s = &sc->segs[node];
+    int prev = start_state;
+    double time_passed = 0.0;
+    for (int i = 0; i < s->K; ++i) {
+      const double r0 = st->rates[s->trip0[i]], r1 = st->rates[s->trip0[i] | 2];
+      const double PT0 = get_trans_prob(st, r0, r1, s->len[i], prev, 0);
+      const double nxt0 = (i == s->K - 1) ? sc->q0[node] : s->p0[i + 1];
+      const double p0 = PT0 * nxt0 / (prev ? s->p1[i] : s->p0[i]);
+      const double u = rng_segment_uniform(g, (uint32_t)node, (uint32_t)i);
+      const int sampled = (u > p0);
+      log_prob += (sampled == 0) ? st->flog(p0) : st->flog(1.0 - p0);
+      ++st->n_segments;
+      if (!overflow)
+        overflow = forward_rejection(st, sc, g, (uint32_t)node, (uint32_t)i, r0, r1, prev,
+                                     sampled, s->len[i], time_passed, pp);
+      log_prob -= st->flog(get_trans_prob(st, r0, r1, s->len[i], prev, sampled));
+      time_passed += s->len[i];
+      prev = sampled;
+    }
+    if (overflow) {
+      /* keep the end state consistent for the children: parity of the jump
+       * count must equal start^prev.  The proposal is rejected anyway. */
+      pp->n = (uint32_t)((start_state ^ prev) & 1);
+    }
+  }
+  *log_prob_out = log_prob;
+  return overflow;
+}
+
+/* SingleSiteSampler.cpp:272-339 */
+static double proposal_prob(const orc_state *st, size_t site, const orc_scratch *sc) {
+  double log_prob = 0.0;
+  for (int node = 1; node < st->n_nodes; ++node) {
+    const orc_segs *s = &sc->segs[node];
+    const orc_path *path = PATH(st, node, site);
+    int start_state = path->init, end_state = path->init;
+    double end_time = 0.0;
+    uint32_t start_jump = 0, end_jump = 0;
+    double lp = 0.0;
+    for (int i = 0; i < s->K; ++i) {
+      end_time += s->len[i];
+      while (end_jump < path->n && path->t[end_jump] < end_time) ++end_jump;
+      if ((end_jump - start_jump) % 2 == 1) end_state ^= 1;
+      const double r0 = st->rates[s->trip0[i]], r1 = st->rates[s->trip0[i] | 2];
+      const double PT0 = get_trans_prob(st, r0, r1, s->len[i], start_state, 0);
+      lp -= st->flog(get_trans_prob(st, r0, r1, s->len[i], start_state, end_state));
+      const double nxt0 = (i == s->K - 1) ? sc->q0[node] : s->p0[i + 1];
+      const double p0 = PT0 / (start_state ? s->p1[i] : s->p0[i]) * nxt0;
+      lp += (end_state == 0) ? st->flog(p0) : st->flog(1.0 - p0);
+      start_jump = end_jump;
+      start_state = end_state;
+    }
+    log_prob += lp;
+  }
+  return log_prob;
+}
+
+/* ------------------------------------------------ sufficient statistics */
+/* Path.cpp:206-301 as one 3-way merge with +inf sentinels.  Tie rules:
+ * left only if strictly below min(mid,right); else mid only if strictly
+ * below right; else right. */
+static void add_suff_stats(const orc_path *l, const orc_path *m, const orc_path *r,
+                           double tot_time, double J[8], double D[8]) {
+  int trip = 4 * l->init + 2 * m->init + r->init;
+  double prev = 0.0;
+  uint32_t i = 0, j = 0, k = 0;
+  for (;;) {
+    const double tl = i < l->n ? l->t[i] : INFINITY;
+    const double tm = j < m->n ? m->t[j] : INFINITY;
+    const double tr = k < r->n ? r->t[k] : INFINITY;
+    if (i >= l->n && j >= m->n && k >= r->n) break;
+    if (tl < (tm < tr ? tm : tr)) {
+      D[trip] += tl - prev; prev = tl; trip ^= 4; ++i;
+    } else if (tm < tr) {
+      D[trip] += tm - prev; J[trip] += 1.0; prev = tm; trip ^= 2; ++j;
+    } else {
+      D[trip] += tr - prev; prev = tr; trip ^= 1; ++k;
+    }
+  }
+  D[trip] += tot_time - prev;
+}
+
+/* SingleSiteSampler.cpp:263-269,342-391.  The root prior is added un-logged
+ * (reference quirk). */
+static double path_llh(const orc_state *st, const orc_path *const *l,
+                       const orc_path *const *m, const orc_path *const *r) {
+  double J[8] = {0, 0, 0, 0, 0, 0, 0, 0}, D[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double llh = st->T[2 * l[1]->init + m[1]->init] * st->T[2 * m[1]->init + r[1]->init];
+  for (int b = 1; b < st->n_nodes; ++b) add_suff_stats(l[b], m[b], r[b], st->blen[b], J, D);
+  double s = 0.0;
+  for (int i = 0; i < 8; ++i) s += J[i] * st->log_rates[i] - D[i] * st->rates[i];
+  llh += s;
+  return llh;
+}
+
+#define ORC_MAX_NODES 4096
+static double site_triple_llh(const orc_state *st, size_t c, const orc_path *prop, int which) {
+  /* llh of the triple centred at c; `prop` (if non-NULL) replaces site
+   * (c + which) where which in {-1,0,+1}. */
+  const orc_path *l[ORC_MAX_NODES], *m[ORC_MAX_NODES], *r[ORC_MAX_NODES];
+  for (int b = 1; b < st->n_nodes; ++b) {
+    l[b] = (prop && which == -1) ? &prop[b] : PATH(st, b, c - 1);
+    m[b] = (prop && which == 0) ? &prop[b] : PATH(st, b, c);
+    r[b] = (prop && which == 1) ? &prop[b] : PATH(st, b, c + 1);
+  }
+  return path_llh(st, l, m, r);
+}
+
+/* ------------------------------------------------------------ MH update */
+/* SingleSiteSampler.cpp:482-536 (+ log_accept_rate :396-433) */
+static int mh_site(orc_state *st, size_t site, uint32_t sweep, orc_scratch *sc) {
+  const size_t n = st->n_sites;
+  for (int node = 1; node < st->n_nodes; ++node)
+    collect_segments(PATH(st, node, site - 1), PATH(st, node, site + 1), st->blen[node],
+                     &sc->segs[node]);
+  pruning(st, site, sc);
+
+  orc_rng g;
+  g.st = st; g.site = (uint32_t)site; g.sweep = sweep;
+  double proposal_log_prob = 0.0;
+  const int overflow = downward_sampling(st, site, sc, &g, &proposal_log_prob);
+
+  double llh_l = st->tri_llh[site - 1];
+  double llh_m = st->tri_llh[site];
+  double llh_r = st->tri_llh[site + 1];
+
+  const double orig_proposal = proposal_prob(st, site, sc);
+  double llr = orig_proposal - proposal_log_prob;
+  const double llh_l_orig = llh_l, llh_r_orig = llh_r;
+  if (!overflow) {
+    if (site > 1) llh_l = site_triple_llh(st, site - 1, sc->prop, 1);
+    llh_m = site_triple_llh(st, site, sc->prop, 0);
+    if (site < n - 2) llh_r = site_triple_llh(st, site + 1, sc->prop, -1);
+  }
+  llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
+
+  const double u = rng_accept_uniform(&g);
+  int accepted = 0;
+  if (llr >= 0 || u < st->fexp(llr)) accepted = 1;
+  if (overflow) { accepted = 0; ++st->n_overflow; }
+
+  if (accepted) {
+    for (int b = 1; b < st->n_nodes; ++b) {
+      orc_path *dst = PATH(st, b, site), *src = &sc->prop[b];
+      orc_path tmp = *dst; *dst = *src; *src = tmp; /* std::swap, :529 */
+    }
+    st->tri_llh[site - 1] = llh_l;
+    st->tri_llh[site] = llh_m;
+    st->tri_llh[site + 1] = llh_r;
+  }
+  return accepted;
+}
+
+/* ------------------------------------------------------------- plumbing */
+static void scratch_init(orc_scratch *sc, int n_nodes) {
+  memset(sc, 0, sizeof(*sc));
+  sc->segs = (orc_segs *)calloc((size_t)n_nodes, sizeof(orc_segs));
+  sc->q0 = (double *)calloc((size_t)n_nodes, sizeof(double));
+  sc->q1 = (double *)calloc((size_t)n_nodes, sizeof(double));
+  sc->prop = (orc_path *)calloc((size_t)n_nodes, sizeof(orc_path));
+}
+static void scratch_free(orc_scratch *sc, int n_nodes) {
+  for (int i = 0; i < n_nodes; ++i) {
+    free(sc->segs[i].len); free(sc->segs[i].trip0); free(sc->segs[i].p0); free(sc->segs[i].p1);
+    free(sc->prop[i].t);
+  }
+  free(sc->segs); free(sc->q0); free(sc->q1); free(sc->prop); free(sc->trial);
+}
+
+static void set_math(orc_state *st) {
+  st->fexp = st->math_mode == ORC_MATH_EPV ? epv_exp_ : libm_exp;
+  st->flog = st->math_mode == ORC_MATH_EPV ? epv_log_ : libm_log;
+}
+
+/* init[(b-1)*n + site], offsets[(b-1)*n + site] (size B*n+1), b = 1..n_nodes-1 */
+ORC_API orc_state *orc_create(uint64_t n_sites, int n_nodes, const uint32_t *parent,
+                              const uint32_t *subtree, const double *branches,
+                              const double *rates, const double *T, const uint8_t *init,
+                              const uint64_t *offsets, const double *jumps) {
+  if (n_nodes < 2 || n_nodes > ORC_MAX_NODES || n_sites < 3) return NULL;
+  orc_state *st = (orc_state *)calloc(1, sizeof(orc_state));
+  st->n_sites = n_sites;
+  st->n_nodes = n_nodes;
+  st->parent = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n_nodes);
+  st->subtree = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n_nodes);
+  st->blen = (double *)malloc(sizeof(double) * (size_t)n_nodes);
+  memcpy(st->parent, parent, sizeof(uint32_t) * (size_t)n_nodes);
+  memcpy(st->subtree, subtree, sizeof(uint32_t) * (size_t)n_nodes);
+  memcpy(st->blen, branches, sizeof(double) * (size_t)n_nodes);
+  memcpy(st->rates, rates, sizeof(double) * 8);
+  memcpy(st->T, T, sizeof(double) * 4);
+  st->paths = (orc_path *)calloc((size_t)n_nodes * n_sites, sizeof(orc_path));
+  st->tri_llh = (double *)calloc(n_sites, sizeof(double));
+  for (int b = 1; b < n_nodes; ++b)
+    for (size_t s = 0; s < n_sites; ++s) {
+      const size_t idx = (size_t)(b - 1) * n_sites + s;
+      orc_path *p = PATH(st, b, s);
+      p->init = init[idx];
+      const uint32_t cnt = (uint32_t)(offsets[idx + 1] - offsets[idx]);
+      if (cnt) {
+        path_reserve(p, cnt);
+        memcpy(p->t, jumps + offsets[idx], cnt * sizeof(double));
+        p->n = cnt;
+      }
+    }
+  st->rng_mode = ORC_RNG_MT;
+  st->math_mode = ORC_MATH_LIBM;
+  st->schedule = ORC_SCHED_SEQ;
+  st->reduce_mode = ORC_REDUCE_SEQ;
+  set_math(st);
+  orc_mt_seed(&st->mt, 5489u);
+  scratch_init(&st->scr, n_nodes);
+  return st;
+}
+
+ORC_API void orc_destroy(orc_state *st) {
+  if (!st) return;
+  for (size_t i = 0; i < (size_t)st->n_nodes * st->n_sites; ++i) free(st->paths[i].t);
+  scratch_free(&st->scr, st->n_nodes);
+  free(st->paths); free(st->tri_llh); free(st->parent); free(st->subtree); free(st->blen);
+  free(st);
+}
+
+ORC_API void orc_set_modes(orc_state *st, int rng_mode, int math_mode, int schedule,
+                           int reduce_mode, uint32_t cap) {
+  st->rng_mode = rng_mode; st->math_mode = math_mode; st->schedule = schedule;
+  st->reduce_mode = reduce_mode; st->cap = cap;
+  set_math(st);
+}
+ORC_API void orc_seed_mt(orc_state *st, uint64_t seed) { orc_mt_seed(&st->mt, (uint32_t)seed); }
+ORC_API void orc_seed_philox(orc_state *st, uint64_t seed) { st->seed = seed; }
+ORC_API void orc_set_model(orc_state *st, const double *rates, const double *T) {
+  memcpy(st->rates, rates, sizeof(double) * 8);
+  memcpy(st->T, T, sizeof(double) * 4);
+}
+
+/* SingleSiteSampler.cpp:449-475.  log(rates) always uses glibc: in the build
+ * it is computed on the host and shipped to the device as constants. */
+ORC_API void orc_reset(orc_state *st) {
+  for (int i = 0; i < 8; ++i) st->log_rates[i] = log(st->rates[i]);
+  for (size_t s = 1; s + 1 < st->n_sites; ++s) st->tri_llh[s] = site_triple_llh(st, s, NULL, 0);
+}
+ORC_API void orc_get_tri_llh(const orc_state *st, double *out) {
+  memcpy(out, st->tri_llh, st->n_sites * sizeof(double));
+}
+
+/* SingleSiteSampler.cpp:538-548 (sequential) or the 3-colour schedule */
+ORC_API uint64_t orc_sweep(orc_state *st, uint32_t sweep) {
+  uint64_t n_acc = 0;
+  const size_t n = st->n_sites;
+  if (st->schedule == ORC_SCHED_SEQ) {
+    for (size_t s = 1; s + 1 < n; ++s) n_acc += (uint64_t)mh_site(st, s, sweep, &st->scr);
+  } else {
+    for (size_t c = 0; c < 3; ++c)
+      for (size_t s = (c == 0 ? 3 : c); s + 1 < n; s += 3)
+        n_acc += (uint64_t)mh_site(st, s, sweep, &st->scr);
+  }
+  return n_acc;
+}
+
+/* one MH update of a single site (epievo_sim_pairwise.cpp:267-273 calls
+ * Metropolis_Hastings_site per site itself) */
+ORC_API int orc_mh_site(orc_state *st, uint64_t site, uint32_t sweep) {
+  return mh_site(st, site, sweep, &st->scr);
+}
+
+/* ParamEstimation.cpp:92-114.  J/D laid out [(b-1)*8 + ctx]. */
+static void site_contrib(const orc_state *st, int b, size_t s, double J[8], double D[8]) {
+  add_suff_stats(PATH(st, b, s - 1), PATH(st, b, s), PATH(st, b, s + 1), st->blen[b], J, D);
+}
+static void tree_sum(const orc_state *st, int b, size_t lo, size_t size, double out[16]) {
+  for (int i = 0; i < 16; ++i) out[i] = 0.0;
+  if (lo >= st->n_sites) return;
+  if (size == 1) {
+    if (lo >= 1 && lo + 1 < st->n_sites) site_contrib(st, b, lo, out, out + 8);
+    return;
+  }
+  double L[16], R[16];
+  tree_sum(st, b, lo, size / 2, L);
+  tree_sum(st, b, lo + size / 2, size / 2, R);
+  for (int i = 0; i < 16; ++i) out[i] = L[i] + R[i];
+}
+ORC_API void orc_suffstats(const orc_state *st, double *J, double *D) {
+  const int B = st->n_nodes - 1;
+  for (int i = 0; i < B * 8; ++i) { J[i] = 0.0; D[i] = 0.0; }
+  if (st->reduce_mode == ORC_REDUCE_SEQ) {
+    for (size_t s = 1; s + 1 < st->n_sites; ++s)
+      for (int b = 1; b <= B; ++b) site_contrib(st, b, s, J + (b - 1) * 8, D + (b - 1) * 8);
+  } else {
+    size_t pad = 1;
+    while (pad < st->n_sites) pad *= 2;
+    for (int b = 1; b <= B; ++b) {
+      double out[16];
+      tree_sum(st, b, 0, pad, out);
+      memcpy(J + (b - 1) * 8, out, 8 * sizeof(double));
+      memcpy(D + (b - 1) * 8, out + 8, 8 * sizeof(double));
+    }
+  }
+}
+
+/* SingleSiteSampler.cpp:550-598.  J/D are batch averages on return. */
+ORC_API void orc_run_mcmc(orc_state *st, uint64_t burn_in, uint64_t batch,
+                          uint32_t sweep_base, double *J, double *D,
+                          uint64_t *n_accepted, double *acc_rate) {
+  const int B = st->n_nodes - 1;
+  uint32_t sweep = sweep_base;
+  for (uint64_t i = 0; i < burn_in; ++i) orc_sweep(st, sweep++);
+  for (int i = 0; i < B * 8; ++i) { J[i] = 0.0; D[i] = 0.0; }
+  double *J1 = (double *)malloc(sizeof(double) * (size_t)B * 8);
+  double *D1 = (double *)malloc(sizeof(double) * (size_t)B * 8);
+  uint64_t n_acc = 0;
+  for (uint64_t i = 0; i < batch; ++i) {
+    n_acc += orc_sweep(st, sweep++);
+    orc_suffstats(st, J1, D1);
+    for (int k = 0; k < B * 8; ++k) { J[k] += J1[k]; D[k] += D1[k]; }
+  }
+  for (int k = 0; k < B * 8; ++k) { J[k] /= (double)batch; D[k] /= (double)batch; }
+  free(J1); free(D1);
+  if (n_accepted) *n_accepted = n_acc;
+  if (acc_rate) *acc_rate = (double)n_acc / (double)(batch * (st->n_sites - 2));
+}
+
+/* ParamEstimation.cpp:369-380 */
+ORC_API void orc_scale_jump_times(orc_state *st, const double *new_branches) {
+  for (size_t s = 0; s < st->n_sites; ++s)
+    for (int b = 1; b < st->n_nodes; ++b) {
+      orc_path *p = PATH(st, b, s);
+      const double scale = new_branches[b] / st->blen[b];
+      for (uint32_t j = 0; j < p->n; ++j) p->t[j] *= scale;
+    }
+  for (int b = 1; b < st->n_nodes; ++b) st->blen[b] = new_branches[b];
+}
+
+ORC_API uint64_t orc_total_jumps(const orc_state *st) {
+  uint64_t tot = 0;
+  for (int b = 1; b < st->n_nodes; ++b)
+    for (size_t s = 0; s < st->n_sites; ++s) tot += PATH(st, b, s)->n;
+  return tot;
+}
+ORC_API void orc_get_paths(const orc_state *st, uint8_t *init, uint64_t *offsets, double *jumps) {
+  uint64_t off = 0;
+  for (int b = 1; b < st->n_nodes; ++b)
+    for (size_t s = 0; s < st->n_sites; ++s) {
+      const size_t idx = (size_t)(b - 1) * st->n_sites + s;
+      const orc_path *p = PATH(st, b, s);
+      init[idx] = p->init;
+      offsets[idx] = off;
+      if (p->n) memcpy(jumps + off, p->t, p->n * sizeof(double));
+      off += p->n;
+    }
+  offsets[(size_t)(st->n_nodes - 1) * st->n_sites] = off;
+}
+ORC_API void orc_get_counters(const orc_state *st, uint64_t *out) {
+  out[0] = st->n_overflow; out[1] = st->n_trials; out[2] = st->n_draws; out[3] = st->n_segments;
+}
+
+/* ------------------------------------------------- per-function KAT hooks */
+ORC_API void orc_kat_trans_prob_mat(int math_mode, double r0, double r1, double t, double *P) {
+  orc_state st; st.math_mode = math_mode; set_math(&st);
+  trans_prob_mat(&st, r0, r1, t, P);
+}
+ORC_API double orc_kat_get_trans_prob(int math_mode, double r0, double r1, double t, int a, int b) {
+  orc_state st; st.math_mode = math_mode; set_math(&st);
+  return get_trans_prob(&st, r0, r1, t, a, b);
+}
+ORC_API int orc_kat_segments(const double *rates, int l_init, uint32_t nl, const double *lj,
+                             int r_init, uint32_t nr, const double *rj, double tot_time,
+                             double *rate0, double *rate1, uint64_t *trip0, uint64_t *trip1,
+                             double *len) {
+  orc_path l = {(uint8_t)l_init, nl, nl, (double *)lj}, r = {(uint8_t)r_init, nr, nr, (double *)rj};
+  orc_segs s; memset(&s, 0, sizeof(s));
+  collect_segments(&l, &r, tot_time, &s);
+  for (int k = 0; k < s.K; ++k) {
+    rate0[k] = rates[s.trip0[k]]; rate1[k] = rates[s.trip0[k] | 2];
+    trip0[k] = s.trip0[k]; trip1[k] = s.trip0[k] | 2; len[k] = s.len[k];
+  }
+  const int K = s.K;
+  free(s.len); free(s.trip0); free(s.p0); free(s.p1);
+  return K;
+}
+ORC_API void orc_kat_suffstats(int l_init, uint32_t nl, const double *lj, int m_init, uint32_t nm,
+                               const double *mj, int r_init, uint32_t nr, const double *rj,
+                               double tot_time, double *J, double *D) {
+  orc_path l = {(uint8_t)l_init, nl, nl, (double *)lj}, m = {(uint8_t)m_init, nm, nm, (double *)mj},
+           r = {(uint8_t)r_init, nr, nr, (double *)rj};
+  add_suff_stats(&l, &m, &r, tot_time, J, D);
+}
+ORC_API double orc_kat_exp(double x) { return orc_exp(x); }
+ORC_API double orc_kat_log(double x) { return orc_log(x); }
+ORC_API void orc_kat_exp_log_array(const double *x, uint64_t n, double *e, double *l) {
+  for (uint64_t i = 0; i < n; ++i) { e[i] = orc_exp(x[i]); l[i] = orc_log(x[i]); }
+}
+ORC_API void orc_kat_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+  orc_philox4x32_10(ctr, key, out);
+}
+ORC_API void orc_kat_keyed_block(uint64_t seed, uint32_t site, uint32_t sweep, uint32_t b,
+                                 uint32_t k, uint32_t t, uint32_t blk, double *d) {
+  orc_keyed_block(seed, site, sweep, b, k, t, blk, d);
+}
+ORC_API void orc_kat_mt_canonical(uint64_t seed, uint64_t n, double *out) {
+  orc_mt19937 g; orc_mt_seed(&g, (uint32_t)seed);
+  for (uint64_t i = 0; i < n; ++i) out[i] = orc_mt_canonical(&g);
+}

@@ -1,0 +1,290 @@
+/* ref_shim.cpp -- TEST INFRASTRUCTURE.  A flat extern "C" face over the
+ * UNMODIFIED reference library (src/libepievo of /root/reference), compiled
+ * where its sources lie by oracle/Makefile into oracle/_ref/.  Nothing of the
+ * reference is copied into this repository: this file only *calls* it, the way
+ * a ~60-line main() of src/prog would (epievo_est_params_histories.cpp:169-264).
+ *
+ * Used (a) to pin the CPU restatement oracle/epv_oracle.c bit-for-bit
+ * (tests/test_oracle_vs_ref.py) and (b) to write the golden fixtures in
+ * tests/golden/ (tests/golden/make_golden.py).  It is only buildable where
+ * /root/reference exists; the built .so travels to the GPU box.
+ */
+#include <limits>
+#include <random>
+#include <vector>
+#include <array>
+#include <string>
+#include <sstream>
+#include <cstring>
+#include <cstdint>
+
+#include "Path.hpp"
+#include "Segment.hpp"
+#include "EpiEvoModel.hpp"
+#include "TreeHelper.hpp"
+#include "ContinuousTimeMarkovModel.hpp"
+#include "SingleSiteSampler.hpp"
+#include "ParamEstimation.hpp"
+
+using std::vector;
+using std::array;
+
+/* defined (non-static) in SingleSiteSampler.cpp:356, not declared in its header */
+double path_log_likelihood(const EpiEvoModel &mod, const vector<Path> &l,
+                           const vector<Path> &m, const vector<Path> &r,
+                           const array<double, 8> &log_rates);
+
+namespace {
+struct RefState {
+  EpiEvoModel model;
+  TreeHelper th;
+  vector<vector<Path> > paths;  // [site][node]
+  std::mt19937 gen;
+  SingleSiteSampler *mcmc;
+  RefState() : mcmc(nullptr) {}
+  ~RefState() { delete mcmc; }
+};
+
+void set_model(EpiEvoModel &m, const double *rates, const double *T) {
+  for (size_t i = 0; i < 8; ++i) m.triplet_rates[i] = rates[i];
+  m.T = two_by_two(T[0], T[1], T[2], T[3]);
+}
+}  // namespace
+
+extern "C" {
+
+void *ref_create(uint64_t n_sites, int n_nodes, const uint32_t *parent,
+                 const uint32_t *subtree, const double *branches, const double *rates,
+                 const double *T, const uint8_t *init, const uint64_t *offsets,
+                 const double *jumps) {
+  RefState *st = new RefState();
+  set_model(st->model, rates, T);
+  st->th.n_nodes = n_nodes;
+  for (int i = 0; i < n_nodes; ++i) {
+    st->th.parent_ids.push_back(parent[i]);
+    st->th.subtree_sizes.push_back(subtree[i]);
+    st->th.branches.push_back(branches[i]);
+    st->th.node_names.push_back("node_" + std::to_string(i));
+  }
+  st->paths.assign(n_sites, vector<Path>(n_nodes));
+  for (int b = 1; b < n_nodes; ++b)
+    for (uint64_t s = 0; s < n_sites; ++s) {
+      const uint64_t idx = (uint64_t)(b - 1) * n_sites + s;
+      Path &p = st->paths[s][b];
+      p.init_state = init[idx];
+      p.tot_time = branches[b];
+      p.jumps.assign(jumps + offsets[idx], jumps + offsets[idx + 1]);
+    }
+  return st;
+}
+
+void ref_destroy(void *h) { delete static_cast<RefState *>(h); }
+
+void ref_set_model(void *h, const double *rates, const double *T) {
+  set_model(static_cast<RefState *>(h)->model, rates, T);
+}
+
+void ref_seed(void *h, uint64_t seed) { static_cast<RefState *>(h)->gen.seed(seed); }
+
+/* SingleSiteSampler(burn_in, batch) + reset(), as est_params_histories.cpp:236,241 */
+void ref_reset(void *h, uint64_t burn_in, uint64_t batch) {
+  RefState *st = static_cast<RefState *>(h);
+  delete st->mcmc;
+  st->mcmc = new SingleSiteSampler(burn_in, batch);
+  st->mcmc->reset(st->model, st->paths);
+}
+
+/* what reset() caches privately: path_log_likelihood of every interior triple */
+void ref_tri_llh(void *h, double *out) {
+  RefState *st = static_cast<RefState *>(h);
+  array<double, 8> log_rates;
+  for (size_t i = 0; i < 8; ++i) log_rates[i] = std::log(st->model.triplet_rates[i]);
+  const size_t n = st->paths.size();
+  for (size_t s = 0; s < n; ++s) out[s] = 0.0;
+  for (size_t s = 1; s + 1 < n; ++s)
+    out[s] = path_log_likelihood(st->model, st->paths[s - 1], st->paths[s], st->paths[s + 1],
+                                 log_rates);
+}
+
+/* sweeps through the public per-site entry, as epievo_sim_pairwise.cpp:267-273 */
+uint64_t ref_sweeps(void *h, uint64_t n_sweeps) {
+  RefState *st = static_cast<RefState *>(h);
+  uint64_t n_acc = 0;
+  for (uint64_t k = 0; k < n_sweeps; ++k)
+    for (size_t s = 1; s + 1 < st->paths.size(); ++s)
+      n_acc += st->mcmc->Metropolis_Hastings_site(st->model, st->th, s, st->paths, st->gen);
+  return n_acc;
+}
+
+int ref_mh_site(void *h, uint64_t site) {
+  RefState *st = static_cast<RefState *>(h);
+  return st->mcmc->Metropolis_Hastings_site(st->model, st->th, site, st->paths, st->gen);
+}
+
+void ref_run_mcmc(void *h, double *J, double *D, double *acc_rate) {
+  RefState *st = static_cast<RefState *>(h);
+  vector<vector<double> > Jv, Dv;
+  double acc = 0.0;
+  st->mcmc->run_mcmc(st->model, st->th, st->paths, st->gen, Jv, Dv, acc);
+  for (size_t b = 1; b < st->th.n_nodes; ++b)
+    for (size_t i = 0; i < 8; ++i) {
+      J[(b - 1) * 8 + i] = Jv[b][i];
+      D[(b - 1) * 8 + i] = Dv[b][i];
+    }
+  *acc_rate = acc;
+}
+
+void ref_suffstats(void *h, double *J, double *D) {
+  RefState *st = static_cast<RefState *>(h);
+  vector<vector<double> > Jv, Dv;
+  get_sufficient_statistics(st->paths, Jv, Dv);
+  for (size_t b = 1; b < st->th.n_nodes; ++b)
+    for (size_t i = 0; i < 8; ++i) {
+      J[(b - 1) * 8 + i] = Jv[b][i];
+      D[(b - 1) * 8 + i] = Dv[b][i];
+    }
+}
+
+void ref_scale_jump_times(void *h, const double *new_branches) {
+  RefState *st = static_cast<RefState *>(h);
+  for (size_t b = 0; b < st->th.n_nodes; ++b) st->th.branches[b] = new_branches[b];
+  scale_jump_times(st->paths, st->th);
+}
+
+uint64_t ref_total_jumps(void *h) {
+  RefState *st = static_cast<RefState *>(h);
+  uint64_t tot = 0;
+  for (size_t s = 0; s < st->paths.size(); ++s)
+    for (size_t b = 1; b < st->th.n_nodes; ++b) tot += st->paths[s][b].jumps.size();
+  return tot;
+}
+
+void ref_get_paths(void *h, uint8_t *init, uint64_t *offsets, double *jumps) {
+  RefState *st = static_cast<RefState *>(h);
+  const size_t n = st->paths.size();
+  uint64_t off = 0;
+  for (size_t b = 1; b < st->th.n_nodes; ++b)
+    for (size_t s = 0; s < n; ++s) {
+      const Path &p = st->paths[s][b];
+      const size_t idx = (b - 1) * n + s;
+      init[idx] = p.init_state;
+      offsets[idx] = off;
+      for (size_t j = 0; j < p.jumps.size(); ++j) jumps[off + j] = p.jumps[j];
+      off += p.jumps.size();
+    }
+  offsets[(st->th.n_nodes - 1) * n] = off;
+}
+
+/* ---- host-side model / M-step (EpiEvoModel.cpp:319-377, ParamEstimation.cpp:337-422) */
+int ref_read_model(const char *param_file, int scale, double *rates, double *T,
+                   double *baseline) {
+  try {
+    EpiEvoModel m;
+    read_model(param_file, m);
+    if (scale) m.scale_triplet_rates();
+    for (size_t i = 0; i < 8; ++i) rates[i] = m.triplet_rates[i];
+    T[0] = m.T(0, 0); T[1] = m.T(0, 1); T[2] = m.T(1, 0); T[3] = m.T(1, 1);
+    baseline[0] = m.stationary_baseline(0, 0); baseline[1] = m.stationary_baseline(0, 1);
+    baseline[2] = m.stationary_baseline(1, 0); baseline[3] = m.stationary_baseline(1, 1);
+    return 0;
+  } catch (...) { return 1; }
+}
+
+/* M-step as est_params_histories.cpp:253-263.  J/D: [(b-1)*8+i].  branches in/out. */
+double ref_m_step(int optimize_branches, int n_nodes, const double *J, const double *D,
+                  double *rates, double *T, double *baseline, double *branches,
+                  char *param_text, int param_text_len) {
+  EpiEvoModel m;
+  array<double, 8> r;
+  for (size_t i = 0; i < 8; ++i) r[i] = rates[i];
+  m.rebuild_from_triplet_rates(r);
+  vector<vector<double> > Jv(n_nodes), Dv(n_nodes);
+  for (int b = 1; b < n_nodes; ++b) {
+    Jv[b].assign(J + (b - 1) * 8, J + b * 8);
+    Dv[b].assign(D + (b - 1) * 8, D + b * 8);
+  }
+  TreeHelper th;
+  th.n_nodes = n_nodes;
+  th.branches.assign(branches, branches + n_nodes);
+  double llh = 0.0;
+  if (!optimize_branches) {
+    llh = estimate_rates(false, 1e-10, Jv, Dv, m);
+    set_one_change_per_site_per_unit_time(m.triplet_rates, th.branches);
+  } else {
+    llh = estimate_rates_and_branches(false, 1e-10, Jv, Dv, th, m);
+  }
+  for (size_t i = 0; i < 8; ++i) rates[i] = m.triplet_rates[i];
+  T[0] = m.T(0, 0); T[1] = m.T(0, 1); T[2] = m.T(1, 0); T[3] = m.T(1, 1);
+  baseline[0] = m.stationary_baseline(0, 0); baseline[1] = m.stationary_baseline(0, 1);
+  baseline[2] = m.stationary_baseline(1, 0); baseline[3] = m.stationary_baseline(1, 1);
+  for (int b = 0; b < n_nodes; ++b) branches[b] = th.branches[b];
+  if (param_text && param_text_len > 0) {
+    const std::string s = m.format_for_param_file();
+    std::strncpy(param_text, s.c_str(), param_text_len - 1);
+    param_text[param_text_len - 1] = '\0';
+  }
+  return llh;
+}
+
+/* ---- per-function known answers */
+int ref_kat_segments(const double *rates, int l_init, uint32_t nl, const double *lj,
+                     int r_init, uint32_t nr, const double *rj, double tot_time,
+                     double *rate0, double *rate1, uint64_t *trip0, uint64_t *trip1,
+                     double *len) {
+  array<double, 8> r;
+  for (size_t i = 0; i < 8; ++i) r[i] = rates[i];
+  Path l(l_init, tot_time, vector<double>(lj, lj + nl));
+  Path rr(r_init, tot_time, vector<double>(rj, rj + nr));
+  vector<SegmentInfo> seg;
+  collect_segment_info(r, l, rr, seg);
+  for (size_t k = 0; k < seg.size(); ++k) {
+    rate0[k] = seg[k].rate0; rate1[k] = seg[k].rate1;
+    trip0[k] = seg[k].trip0; trip1[k] = seg[k].trip1; len[k] = seg[k].len;
+  }
+  return (int)seg.size();
+}
+
+void ref_kat_trans_prob_mat(double r0, double r1, double t, double *P) {
+  two_by_two M;
+  continuous_time_trans_prob_mat(r0, r1, t, M);
+  P[0] = M(0, 0); P[1] = M(0, 1); P[2] = M(1, 0); P[3] = M(1, 1);
+}
+
+double ref_kat_get_trans_prob(double r0, double r1, double t, int a, int b) {
+  const TwoStateCTMarkovModel ctmm(r0, r1);
+  return ctmm.get_trans_prob(t, a, b);
+}
+
+void ref_kat_suffstats(int l_init, uint32_t nl, const double *lj, int m_init, uint32_t nm,
+                       const double *mj, int r_init, uint32_t nr, const double *rj,
+                       double tot_time, double *J, double *D) {
+  Path l(l_init, tot_time, vector<double>(lj, lj + nl));
+  Path m(m_init, tot_time, vector<double>(mj, mj + nm));
+  Path r(r_init, tot_time, vector<double>(rj, rj + nr));
+  vector<double> Jv(J, J + 8), Dv(D, D + 8);
+  add_sufficient_statistics(l, m, r, Jv, Dv);
+  for (size_t i = 0; i < 8; ++i) { J[i] = Jv[i]; D[i] = Dv[i]; }
+}
+
+/* closed-form E[J], E[D] of an end-conditioned 2-state path
+ * (ContinuousTimeMarkovModel.cpp:168-226): a known-answer source for the means
+ * of ANY exact end-conditioned sampler. out: J0,J1,D0,D1 each 4 doubles. */
+void ref_kat_expectations(double r0, double r1, double T, double *out) {
+  two_by_two J0, J1, D0, D1;
+  expectation_J(r0, r1, T, J0, J1);
+  expectation_D(r0, r1, T, D0, D1);
+  const two_by_two *m[4] = {&J0, &J1, &D0, &D1};
+  for (int k = 0; k < 4; ++k) {
+    out[4 * k + 0] = (*m[k])(0, 0); out[4 * k + 1] = (*m[k])(0, 1);
+    out[4 * k + 2] = (*m[k])(1, 0); out[4 * k + 3] = (*m[k])(1, 1);
+  }
+}
+
+/* libstdc++ draws, to pin orc_mt_canonical */
+void ref_kat_mt_canonical(uint64_t seed, uint64_t n, double *out) {
+  std::mt19937 g(seed);
+  std::uniform_real_distribution<double> u(0.0, 1.0);
+  for (uint64_t i = 0; i < n; ++i) out[i] = u(g);
+}
+
+}  // extern "C"
