@@ -1,0 +1,610 @@
+// epv_abi.hip -- the extern "C" boundary of include/epievo_mi355x.h: device memory,
+// stream, launches.  No torch types, no exceptions across the boundary, no CPU
+// fallback: when HIP is unavailable every entry point fails with EPV_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "epievo_mi355x.h"
+#include "epv_device.h"
+
+#define EPV_API extern "C" __attribute__((visibility("default")))
+
+#include "epv_kernels.h"  // all __global__ kernels (single translation unit, no -fgpu-rdc)
+
+struct epv_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  EpvDev S{};
+  bool have_tree = false, have_model = false, have_paths = false, have_reset = false;
+  // host copies
+  std::vector<uint32_t> parent, subtree;
+  std::vector<double> blen;
+  EpvModelConst model{};
+  uint64_t first = 0, last = 0;
+  // device allocations
+  EpvModelConst *d_model = nullptr;
+  uint32_t *d_parent = nullptr, *d_subtree = nullptr;
+  double *d_blen = nullptr;
+  unsigned long long *d_counters = nullptr;
+  double *d_partial[2] = {nullptr, nullptr};  // tree-reduction ping-pong
+  uint64_t partial_cap = 0;
+  double *d_jd_acc = nullptr;  // [B*16] accumulated over batch sweeps
+  double *d_scale = nullptr;
+  // launch shape of the MH kernel
+  uint32_t mh_threads = 64, pool_entries = 0;
+  double kbar = 0.0;  // mean jumps per (site, branch) of the uploaded paths
+  size_t mh_lds = 0;
+  // counters / timing
+  uint64_t n_sweeps = 0, tot_overflow = 0, tot_coop = 0;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double timed_ms = 0.0;
+  uint64_t timed_launches = 0;
+};
+
+namespace {
+
+int fail(epv_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define HIP_TRY(c, call)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail((c), EPV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+void dfree(T *&p) {
+  if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+void free_paths(epv_ctx *c) {
+  dfree(c->S.meta); dfree(c->S.jumps); dfree(c->S.sel); dfree(c->S.tri);
+  dfree(c->d_partial[0]); dfree(c->d_partial[1]);
+  c->partial_cap = 0;
+  c->have_paths = c->have_reset = false;
+}
+
+size_t const_lds_bytes(uint32_t N) { return (size_t)((20u + N + 1u) & ~1u) * 8u; }
+
+// choose the MH launch shape: one wave per block; the record pool is as large as fits
+// six blocks per CU, but never smaller than one lane's worst case
+int plan_mh(epv_ctx *c) {
+  const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
+  const uint64_t worst = (uint64_t)B * (2u * C + 2u);
+  const size_t fixed = const_lds_bytes(N) + (size_t)N * 128u * 8u;
+  if (fixed + worst * 32u > 160u * 1024u)
+    return fail(c, EPV_ERR_ARG, "tree/capacity too large for the 160 KiB LDS record pool");
+  // typical demand of 64 lanes: B * (2 kbar + 2) records each, with a 30 % margin
+  const uint64_t typical = (uint64_t)(64.0 * B * (2.0 * c->kbar + 2.0) * 1.3) + 32u;
+  const uint64_t max_fit = (160u * 1024u - fixed) / 32u;
+  const uint64_t pool = std::min<uint64_t>(std::max<uint64_t>(worst, typical), max_fit);
+  const size_t lds = fixed + (size_t)pool * 32u;
+  c->mh_threads = 64;
+  c->pool_entries = (uint32_t)pool;
+  c->mh_lds = lds;
+  return EPV_OK;
+}
+
+int ensure_partials(epv_ctx *c) {
+  const uint64_t nb = (c->S.n + 255u) / 256u;
+  const uint64_t V = (uint64_t)c->S.B * 16u;
+  if (c->partial_cap >= nb * V) return EPV_OK;
+  dfree(c->d_partial[0]); dfree(c->d_partial[1]);
+  HIP_TRY(c, hipMalloc(&c->d_partial[0], nb * V * sizeof(double)));
+  HIP_TRY(c, hipMalloc(&c->d_partial[1], ((nb + 255u) / 256u) * V * sizeof(double)));
+  c->partial_cap = nb * V;
+  return EPV_OK;
+}
+
+// J/D of the current paths into d_partial[x][0..V); returns the buffer index via *which
+int launch_suffstats(epv_ctx *c, int *which) {
+  int rc = ensure_partials(c);
+  if (rc) return rc;
+  const uint64_t nb = (c->S.n + 255u) / 256u;
+  const uint32_t V = c->S.B * 16u;
+  hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)nb), dim3(256), const_lds_bytes(c->S.N),
+                     c->stream, c->S, c->first, c->last, c->d_partial[0]);
+  uint64_t m = nb;
+  int cur = 0;
+  while (m > 1) {
+    const uint64_t mb = (m + 255u) / 256u;
+    hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb), dim3(256), 0, c->stream,
+                       c->d_partial[cur], m, V, c->d_partial[cur ^ 1]);
+    m = mb;
+    cur ^= 1;
+  }
+  HIP_TRY(c, hipGetLastError());
+  *which = cur;
+  return EPV_OK;
+}
+
+int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
+  const uint64_t span = c->last - c->first + 1u;
+  const uint64_t threads = (span + 2u) / 3u;
+  const uint64_t blocks = (threads + c->mh_threads - 1u) / c->mh_threads;
+  if (blocks == 0) return EPV_OK;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->timing) {
+    if (c->ev_used == c->ev_pool.size()) {
+      hipEvent_t a, b;
+      HIP_TRY(c, hipEventCreate(&a));
+      HIP_TRY(c, hipEventCreate(&b));
+      c->ev_pool.emplace_back(a, b);
+    }
+    e0 = c->ev_pool[c->ev_used].first;
+    e1 = c->ev_pool[c->ev_used].second;
+    ++c->ev_used;
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+  }
+  hipLaunchKernelGGL(epv_mh_phase_kernel, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds,
+                     c->stream, c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32),
+                     sweep, c->first, c->last, c->pool_entries, c->d_counters);
+  if (c->timing) HIP_TRY(c, hipEventRecord(e1, c->stream));
+  HIP_TRY(c, hipGetLastError());
+  return EPV_OK;
+}
+
+// fold finished timing events into the running totals (stream must be idle)
+int drain_timing(epv_ctx *c) {
+  for (size_t i = 0; i < c->ev_used; ++i) {
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+    c->timed_ms += ms;
+    ++c->timed_launches;
+  }
+  c->ev_used = 0;
+  return EPV_OK;
+}
+
+int read_counters(epv_ctx *c, unsigned long long out[EPV_CNT_N]) {
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_counters, sizeof(unsigned long long) * EPV_CNT_N,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return drain_timing(c);
+}
+
+int check_ready(epv_ctx *c, bool need_reset) {
+  if (!c) return EPV_ERR_ARG;
+  if (!c->have_tree || !c->have_model || !c->have_paths)
+    return fail(c, EPV_ERR_STATE, "tree, model and paths must be set first");
+  if (need_reset && !c->have_reset) return fail(c, EPV_ERR_STATE, "epv_reset has not been called");
+  return EPV_OK;
+}
+
+}  // namespace
+
+EPV_API epv_ctx *epv_create(int device_id) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count) return nullptr;
+  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  epv_ctx *c = new epv_ctx();
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(&c->d_model, sizeof(EpvModelConst)) != hipSuccess ||
+      hipMalloc(&c->d_counters, sizeof(unsigned long long) * EPV_CNT_N) != hipSuccess ||
+      hipMemset(c->d_counters, 0, sizeof(unsigned long long) * EPV_CNT_N) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  // the MH kernel asks for more dynamic LDS than the 64 KiB default
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_phase_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return c;
+}
+
+EPV_API void epv_destroy(epv_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_paths(c);
+  dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
+  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale);
+  for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+EPV_API const char *epv_last_error(const epv_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+EPV_API int epv_set_tree(epv_ctx *c, int n_nodes, const uint32_t *parent_ids,
+                         const uint32_t *subtree_sizes, const double *branches) {
+  if (!c) return EPV_ERR_ARG;
+  if (n_nodes < 2 || n_nodes > 4095 || !parent_ids || !subtree_sizes || !branches)
+    return fail(c, EPV_ERR_ARG, "bad tree");
+  if (c->have_paths && (uint32_t)n_nodes != c->S.N)
+    return fail(c, EPV_ERR_ARG, "tree size differs from the uploaded paths");
+  for (int i = 1; i < n_nodes; ++i)
+    if (parent_ids[i] >= (uint32_t)i || subtree_sizes[i] < 1 || i + subtree_sizes[i] > (uint32_t)n_nodes ||
+        !(branches[i] > 0.0))
+      return fail(c, EPV_ERR_ARG, "tree arrays are not a valid pre-order tree with positive branches");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->parent.assign(parent_ids, parent_ids + n_nodes);
+  c->subtree.assign(subtree_sizes, subtree_sizes + n_nodes);
+  c->blen.assign(branches, branches + n_nodes);
+  dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen); dfree(c->d_jd_acc); dfree(c->d_scale);
+  HIP_TRY(c, hipMalloc(&c->d_parent, sizeof(uint32_t) * n_nodes));
+  HIP_TRY(c, hipMalloc(&c->d_subtree, sizeof(uint32_t) * n_nodes));
+  HIP_TRY(c, hipMalloc(&c->d_blen, sizeof(double) * n_nodes));
+  HIP_TRY(c, hipMalloc(&c->d_jd_acc, sizeof(double) * (n_nodes - 1) * 16));
+  HIP_TRY(c, hipMalloc(&c->d_scale, sizeof(double) * n_nodes));
+  HIP_TRY(c, hipMemcpy(c->d_parent, parent_ids, sizeof(uint32_t) * n_nodes, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_subtree, subtree_sizes, sizeof(uint32_t) * n_nodes, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_blen, branches, sizeof(double) * n_nodes, hipMemcpyHostToDevice));
+  c->S.N = (uint32_t)n_nodes;
+  c->S.B = (uint32_t)n_nodes - 1u;
+  c->S.parent = c->d_parent;
+  c->S.subtree = c->d_subtree;
+  c->S.blen = c->d_blen;
+  c->have_tree = true;
+  c->have_reset = false;
+  if (c->have_paths) return plan_mh(c);
+  return EPV_OK;
+}
+
+EPV_API int epv_set_model(epv_ctx *c, const double *triplet_rates, const double *T) {
+  if (!c) return EPV_ERR_ARG;
+  if (!triplet_rates || !T) return fail(c, EPV_ERR_ARG, "null model");
+  for (int i = 0; i < 8; ++i) {
+    if (!(triplet_rates[i] > 0.0)) return fail(c, EPV_ERR_ARG, "triplet rates must be positive");
+    c->model.rates[i] = triplet_rates[i];
+    c->model.log_rates[i] = std::log(triplet_rates[i]);  // SingleSiteSampler.cpp:464-468
+  }
+  for (int i = 0; i < 4; ++i) c->model.T[i] = T[i];
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy(c->d_model, &c->model, sizeof(EpvModelConst), hipMemcpyHostToDevice));
+  c->S.model = c->d_model;
+  c->have_model = true;
+  c->have_reset = false;
+  return EPV_OK;
+}
+
+EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_state,
+                             const uint64_t *offsets, const double *jumps, uint32_t capacity,
+                             uint64_t global_site_offset) {
+  if (!c) return EPV_ERR_ARG;
+  if (!c->have_tree) return fail(c, EPV_ERR_STATE, "epv_set_tree must come before epv_upload_paths");
+  if (n_sites < 3 || !init_state || !offsets) return fail(c, EPV_ERR_ARG, "bad paths");
+  if (global_site_offset + n_sites > 0xffffffffull)
+    return fail(c, EPV_ERR_ARG, "site indices must fit 32 bits (Philox counter word)");
+  const uint64_t B = c->S.B, E = B * n_sites;
+  uint64_t maxj = 0;
+  for (uint64_t e = 0; e < E; ++e) {
+    if (offsets[e + 1] < offsets[e]) return fail(c, EPV_ERR_ARG, "offsets must be non-decreasing");
+    maxj = std::max<uint64_t>(maxj, offsets[e + 1] - offsets[e]);
+  }
+  if (capacity == 0) capacity = (uint32_t)std::max<uint64_t>(16u, 2u * maxj + 8u);
+  if (capacity > EPV_MAX_CAP) capacity = EPV_MAX_CAP;
+  if (maxj > capacity) return fail(c, EPV_ERR_CAPACITY, "an input path has more jumps than the capacity");
+  HIP_TRY(c, hipSetDevice(c->device));
+  free_paths(c);
+  c->S.n = n_sites;
+  c->S.g0 = global_site_offset;
+  c->S.n_global = global_site_offset + n_sites;
+  c->S.C = capacity;
+  c->kbar = E ? (double)offsets[E] / (double)E : 0.0;
+  HIP_TRY(c, hipMalloc(&c->S.meta, 2u * E));
+  HIP_TRY(c, hipMalloc(&c->S.jumps, 2u * E * capacity * sizeof(double)));
+  HIP_TRY(c, hipMalloc(&c->S.sel, n_sites));
+  HIP_TRY(c, hipMalloc(&c->S.tri, n_sites * sizeof(double)));
+  HIP_TRY(c, hipMemsetAsync(c->S.meta, 0, 2u * E, c->stream));
+  // staging of the CSR form
+  uint8_t *d_init = nullptr;
+  uint64_t *d_off = nullptr;
+  double *d_j = nullptr;
+  const uint64_t tot = offsets[E];
+  HIP_TRY(c, hipMalloc(&d_init, E));
+  HIP_TRY(c, hipMalloc(&d_off, (E + 1) * sizeof(uint64_t)));
+  HIP_TRY(c, hipMalloc(&d_j, std::max<uint64_t>(tot, 1) * sizeof(double)));
+  HIP_TRY(c, hipMemcpyAsync(d_init, init_state, E, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_off, offsets, (E + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  if (tot) HIP_TRY(c, hipMemcpyAsync(d_j, jumps, tot * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(epv_scatter_kernel, dim3((unsigned)((E + 255u) / 256u)), dim3(256), 0, c->stream,
+                     c->S, d_init, d_off, d_j);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_init); (void)hipFree(d_off); (void)hipFree(d_j);
+  c->first = 1;
+  c->last = n_sites - 2;
+  c->have_paths = true;
+  c->have_reset = false;
+  return plan_mh(c);
+}
+
+EPV_API int epv_set_global_length(epv_ctx *c, uint64_t n_global) {
+  if (!c || !c->have_paths) return EPV_ERR_ARG;
+  if (n_global < c->S.g0 + c->S.n) return fail(c, EPV_ERR_ARG, "n_global smaller than the shard");
+  c->S.n_global = n_global;
+  return EPV_OK;
+}
+
+EPV_API int epv_set_update_range(epv_ctx *c, uint64_t first, uint64_t last) {
+  if (!c || !c->have_paths) return EPV_ERR_ARG;
+  if (first < 1 || last > c->S.n - 2 || first > last) return fail(c, EPV_ERR_ARG, "bad update range");
+  if (c->S.g0 + first > 1 && first < 2) return fail(c, EPV_ERR_ARG, "shard needs a 2-site left halo");
+  if (c->S.g0 + last < c->S.n_global - 2 && last > c->S.n - 3)
+    return fail(c, EPV_ERR_ARG, "shard needs a 2-site right halo");
+  c->first = first;
+  c->last = last;
+  return EPV_OK;
+}
+
+EPV_API int epv_reset(epv_ctx *c) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(epv_reset_kernel, dim3((unsigned)((c->S.n + 255u) / 256u)), dim3(256),
+                     const_lds_bytes(c->S.N), c->stream, c->S);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_reset = true;
+  return EPV_OK;
+}
+
+static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base) {
+  unsigned long long cnt[EPV_CNT_N];
+  int rc = read_counters(c, cnt);
+  if (rc) return rc;
+  if (n_accepted) *n_accepted = cnt[EPV_CNT_ACCEPT] - acc_base;
+  const uint64_t new_ovf = cnt[EPV_CNT_OVERFLOW] - c->tot_overflow;
+  c->tot_overflow = cnt[EPV_CNT_OVERFLOW];
+  c->tot_coop = cnt[EPV_CNT_COOP];
+  if (new_ovf) {
+    char buf[160];
+    std::snprintf(buf, sizeof buf,
+                  "%llu proposals needed more than %u jumps on a branch and were rejected; "
+                  "re-upload with a larger capacity",
+                  (unsigned long long)new_ovf, c->S.C);
+    return fail(c, EPV_ERR_CAPACITY, buf);
+  }
+  return EPV_OK;
+}
+
+static int current_accepts(epv_ctx *c, uint64_t *out) {
+  unsigned long long cnt[EPV_CNT_N];
+  int rc = read_counters(c, cnt);
+  if (rc) return rc;
+  *out = cnt[EPV_CNT_ACCEPT];
+  return EPV_OK;
+}
+
+EPV_API int epv_sweep_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep,
+                            uint64_t *n_accepted) {
+  int rc = check_ready(c, true);
+  if (rc) return rc;
+  if (colour < 0 || colour > 2) return fail(c, EPV_ERR_ARG, "colour must be 0, 1 or 2");
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint64_t base = 0;
+  if ((rc = current_accepts(c, &base))) return rc;
+  if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
+  return finish_mcmc(c, n_accepted, base);
+}
+
+EPV_API int epv_sweep(epv_ctx *c, uint64_t n_sweeps, uint64_t seed, uint32_t sweep_base,
+                      uint64_t *n_accepted) {
+  int rc = check_ready(c, true);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint64_t base = 0;
+  if ((rc = current_accepts(c, &base))) return rc;
+  for (uint64_t w = 0; w < n_sweeps; ++w) {
+    for (int colour = 0; colour < 3; ++colour)
+      if ((rc = launch_phase(c, colour, seed, sweep_base + (uint32_t)w))) return rc;
+    ++c->n_sweeps;
+  }
+  return finish_mcmc(c, n_accepted, base);
+}
+
+EPV_API int epv_run_mcmc(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint64_t seed,
+                         uint32_t sweep_base, double *J, double *D, uint64_t *n_accepted) {
+  int rc = check_ready(c, true);
+  if (rc) return rc;
+  if (!J || !D || batch == 0) return fail(c, EPV_ERR_ARG, "bad run_mcmc arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t V = c->S.B * 16u;
+  uint32_t sweep = sweep_base;
+  for (uint64_t w = 0; w < burn_in; ++w, ++sweep) {
+    for (int colour = 0; colour < 3; ++colour)
+      if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
+    ++c->n_sweeps;
+  }
+  uint64_t base = 0;
+  if ((rc = current_accepts(c, &base))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->d_jd_acc, 0, V * sizeof(double), c->stream));
+  for (uint64_t w = 0; w < batch; ++w, ++sweep) {
+    for (int colour = 0; colour < 3; ++colour)
+      if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
+    ++c->n_sweeps;
+    int which = 0;
+    if ((rc = launch_suffstats(c, &which))) return rc;
+    hipLaunchKernelGGL(epv_accumulate_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream,
+                       c->d_jd_acc, c->d_partial[which], V);
+  }
+  HIP_TRY(c, hipGetLastError());
+  std::vector<double> jd(V);
+  HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_jd_acc, V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  rc = finish_mcmc(c, n_accepted, base);  // synchronises the stream
+  const double nb = (double)batch;
+  for (uint32_t b = 0; b < c->S.B; ++b)
+    for (int k = 0; k < 8; ++k) {
+      J[b * 8 + k] = jd[b * 16 + k] / nb;       // batch average, SingleSiteSampler.cpp:589-594
+      D[b * 8 + k] = jd[b * 16 + 8 + k] / nb;
+    }
+  return rc;
+}
+
+EPV_API int epv_get_sufficient_statistics(epv_ctx *c, double *J, double *D) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int which = 0;
+  if ((rc = launch_suffstats(c, &which))) return rc;
+  const uint32_t V = c->S.B * 16u;
+  std::vector<double> jd(V);
+  HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_partial[which], V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t b = 0; b < c->S.B; ++b)
+    for (int k = 0; k < 8; ++k) {
+      J[b * 8 + k] = jd[b * 16 + k];
+      D[b * 8 + k] = jd[b * 16 + 8 + k];
+    }
+  return EPV_OK;
+}
+
+EPV_API int epv_scale_jump_times(epv_ctx *c, const double *new_branches) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<double> scale(c->S.N, 1.0);
+  for (uint32_t b = 1; b < c->S.N; ++b) {
+    if (!(new_branches[b] > 0.0)) return fail(c, EPV_ERR_ARG, "branch lengths must be positive");
+    scale[b] = new_branches[b] / c->blen[b];  // ParamEstimation.cpp:372
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_scale, scale.data(), sizeof(double) * c->S.N, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(epv_scale_kernel, dim3((unsigned)((c->S.n + 255u) / 256u)), dim3(256), 0,
+                     c->stream, c->S, c->d_scale);
+  HIP_TRY(c, hipGetLastError());
+  for (uint32_t b = 1; b < c->S.N; ++b) c->blen[b] = new_branches[b];
+  HIP_TRY(c, hipMemcpyAsync(c->d_blen, c->blen.data(), sizeof(double) * c->S.N, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_reset = false;  // cached log-likelihoods are stale, as in the reference
+  return EPV_OK;
+}
+
+static int export_paths(epv_ctx *c, uint8_t *init_state, uint64_t *offsets, double *jumps,
+                        uint64_t *total) {
+  const uint64_t E = (uint64_t)c->S.B * c->S.n;
+  uint8_t *d_init = nullptr;
+  uint64_t *d_cnt = nullptr;
+  HIP_TRY(c, hipMalloc(&d_init, E));
+  HIP_TRY(c, hipMalloc(&d_cnt, (E + 1) * sizeof(uint64_t)));
+  hipLaunchKernelGGL(epv_count_kernel, dim3((unsigned)((E + 255u) / 256u)), dim3(256), 0, c->stream,
+                     c->S, d_init, d_cnt);
+  std::vector<uint64_t> off(E + 1);
+  HIP_TRY(c, hipMemcpyAsync(off.data(), d_cnt, E * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint64_t run = 0;
+  for (uint64_t e = 0; e < E; ++e) { const uint64_t k = off[e]; off[e] = run; run += k; }
+  off[E] = run;
+  if (total) *total = run;
+  if (offsets) {
+    std::memcpy(offsets, off.data(), (E + 1) * sizeof(uint64_t));
+    HIP_TRY(c, hipMemcpy(init_state, d_init, E, hipMemcpyDeviceToHost));
+    if (run) {
+      double *d_j = nullptr;
+      HIP_TRY(c, hipMalloc(&d_j, run * sizeof(double)));
+      HIP_TRY(c, hipMemcpyAsync(d_cnt, off.data(), (E + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(epv_gather_kernel, dim3((unsigned)((E + 255u) / 256u)), dim3(256), 0,
+                         c->stream, c->S, d_cnt, d_j);
+      HIP_TRY(c, hipMemcpyAsync(jumps, d_j, run * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(d_j);
+    }
+  }
+  (void)hipFree(d_init); (void)hipFree(d_cnt);
+  return EPV_OK;
+}
+
+EPV_API int epv_paths_total_jumps(epv_ctx *c, uint64_t *total) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  return export_paths(c, nullptr, nullptr, nullptr, total);
+}
+
+EPV_API int epv_download_paths(epv_ctx *c, uint8_t *init_state, uint64_t *offsets, double *jumps) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (!init_state || !offsets) return fail(c, EPV_ERR_ARG, "null output");
+  HIP_TRY(c, hipSetDevice(c->device));
+  return export_paths(c, init_state, offsets, jumps, nullptr);
+}
+
+EPV_API int epv_get_tri_llh(epv_ctx *c, double *out) {
+  int rc = check_ready(c, true);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy(out, c->S.tri, c->S.n * sizeof(double), hipMemcpyDeviceToHost));
+  return EPV_OK;
+}
+
+EPV_API uint64_t epv_column_bytes(const epv_ctx *c) {
+  if (!c || !c->have_paths) return 0;
+  return (((uint64_t)c->S.B + 7u) & ~7ull) + ((uint64_t)c->S.B * c->S.C + 3u) * 8u;
+}
+
+EPV_API int epv_get_columns(epv_ctx *c, uint64_t first, uint64_t count, void *packed) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (first + count > c->S.n || !packed) return fail(c, EPV_ERR_ARG, "bad column range");
+  if (count == 0) return EPV_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t bytes = count * epv_column_bytes(c);
+  uint8_t *d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, bytes));
+  hipLaunchKernelGGL(epv_pack_columns_kernel, dim3((unsigned)count), dim3(64), 0, c->stream, c->S,
+                     first, count, d);
+  HIP_TRY(c, hipMemcpyAsync(packed, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  return EPV_OK;
+}
+
+EPV_API int epv_put_columns(epv_ctx *c, uint64_t first, uint64_t count, const void *packed) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (first + count > c->S.n || !packed) return fail(c, EPV_ERR_ARG, "bad column range");
+  if (count == 0) return EPV_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t bytes = count * epv_column_bytes(c);
+  uint8_t *d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, bytes));
+  HIP_TRY(c, hipMemcpyAsync(d, packed, bytes, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(epv_unpack_columns_kernel, dim3((unsigned)count), dim3(64), 0, c->stream, c->S,
+                     first, count, d);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  return EPV_OK;
+}
+
+EPV_API int epv_get_counters(epv_ctx *c, epv_counters *out) {
+  if (!c || !out) return EPV_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  unsigned long long cnt[EPV_CNT_N];
+  int rc = read_counters(c, cnt);
+  if (rc) return rc;
+  out->n_overflow = cnt[EPV_CNT_OVERFLOW];
+  out->n_coop_tasks = cnt[EPV_CNT_COOP];
+  out->n_sweeps = c->n_sweeps;
+  out->reserved = 0;
+  return EPV_OK;
+}
+
+EPV_API int epv_set_timing(epv_ctx *c, int enabled) {
+  if (!c) return EPV_ERR_ARG;
+  c->timing = enabled != 0;
+  return EPV_OK;
+}
+
+EPV_API int epv_kernel_time_ms(epv_ctx *c, double *avg_ms, uint64_t *n_launches) {
+  if (!c || !avg_ms || !n_launches) return EPV_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = drain_timing(c);
+  if (rc) return rc;
+  *n_launches = c->timed_launches;
+  *avg_ms = c->timed_launches ? c->timed_ms / (double)c->timed_launches : 0.0;
+  c->timed_ms = 0.0;
+  c->timed_launches = 0;
+  return EPV_OK;
+}

@@ -1,0 +1,47 @@
+// epv_device.h -- device-side data layout shared by the kernels and the ABI glue.
+//
+// HBM layout (SoA, "jump times packed as SoA for coalesced access"):
+//   meta [2][B][n]     u8   bit7 = Path::init_state, bits0-6 = number of jumps
+//   jumps[2][B][C][n]  f64  jump k of (buffer, branch, site) at ((buf*B+b)*C+k)*n+site
+//   sel  [n]           u8   which of the two buffers holds the CURRENT path of a site
+//   tri  [n]           f64  cached complete-data log-likelihood of the triple centred
+//                           at each site (SingleSiteSampler's private tri_llh)
+// Lanes of a wavefront map to sites, so meta/sel/tri/jump-plane loads are unit- or
+// stride-3-coalesced.  The proposal of a site is written straight into the site's
+// OTHER buffer; accepting it is a one-byte flip of sel[site] (no copy), rejecting it
+// costs nothing.
+#ifndef EPV_DEVICE_H
+#define EPV_DEVICE_H
+
+#include <stdint.h>
+
+#define EPV_MAX_CAP 127u
+#define EPV_WAVE 64
+
+struct EpvModelConst {  // staged into LDS by every block
+  double rates[8];
+  double log_rates[8];
+  double T[4];
+};
+
+struct EpvDev {
+  uint64_t n;        // local sites
+  uint64_t g0;       // global index of local site 0
+  uint64_t n_global; // genome length (for the two global boundary special cases)
+  uint32_t B;        // branches = n_nodes - 1
+  uint32_t C;        // jump capacity per (site, branch)
+  uint32_t N;        // nodes
+  uint8_t *meta;
+  double *jumps;
+  uint8_t *sel;
+  double *tri;
+  const EpvModelConst *model;  // device copy
+  const uint32_t *parent;      // [N]
+  const uint32_t *subtree;     // [N]
+  const double *blen;          // [N]
+};
+
+// counters[] slots
+enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_N = 4 };
+
+#endif

@@ -1,0 +1,689 @@
+#ifndef EPV_KERNELS_H
+#define EPV_KERNELS_H
+// epv_kernels.h -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for epievo's
+// MCEM inner loop.  One lane = one genomic site; one launch = one colour phase of the
+// 3-colour sweep (sites congruent mod 3 are conditionally independent and
+// write-disjoint).  No MFMA: this is an fp64 latency/divergence-bound
+// sampler, not a contraction.
+//
+// What each kernel replaces in the reference (/root/reference/src/libepievo):
+//   epv_mh_phase_kernel    SingleSiteSampler::Metropolis_Hastings_site (SingleSiteSampler.cpp:482-536)
+//                          = collect_segment_info (Segment.cpp:35-79) + pruning (:145-157)
+//                          + downward_sampling (:227-255) + end_cond_sample_forward_rejection
+//                          (EndCondSampling.cpp:479-509) + log_accept_rate (:396-433)
+//   epv_reset_kernel       SingleSiteSampler::reset (:449-475)
+//   epv_suffstat_kernel    get_sufficient_statistics (ParamEstimation.cpp:92-114)
+//   epv_tree_reduce_kernel (the upper levels of the canonical binary-tree reduction)
+//   epv_scale_kernel       scale_jump_times (ParamEstimation.cpp:369-380)
+//
+// Arithmetic contract: every fp64 operation follows the order of the reference
+// expression it restates; the file is compiled -ffp-contract=off; exp/log are the
+// deterministic epv_exp/epv_log.  The CPU oracle (oracle/epv_oracle.c, rung B) makes
+// the same choices independently, and tests/test_gpu_parity.py demands bit equality.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "epv_device.h"
+#include "epv_math.h"
+#include "epv_philox.h"
+
+#define EPV_INF __builtin_inf()
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ int epv_lane() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int lane = epv_lane();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_xor(v, d);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  const uint64_t u = epv_d2u(v);
+  const uint32_t lo = __shfl((uint32_t)u, src), hi = __shfl((uint32_t)(u >> 32), src);
+  return epv_u2d(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  const uint64_t u = epv_d2u(v);
+  const uint32_t lo = __shfl_xor((uint32_t)u, m), hi = __shfl_xor((uint32_t)(u >> 32), m);
+  return epv_u2d(((uint64_t)hi << 32) | lo);
+}
+
+// ------------------------------------------------------------------ path access
+struct PathRef {
+  const double *j;  // jump k lives at j[k * n]
+  uint32_t nj;
+  uint32_t init;
+};
+__device__ __forceinline__ PathRef path_ref(const EpvDev &S, uint32_t buf, uint32_t b,
+                                            uint64_t site) {
+  const uint64_t plane = (uint64_t)buf * S.B + b;
+  const uint8_t m = S.meta[plane * S.n + site];
+  PathRef p;
+  p.j = S.jumps + plane * S.C * S.n + site;
+  p.nj = m & 127u;
+  p.init = m >> 7;
+  return p;
+}
+
+// ------------------------------------------------ sufficient statistics of a triple
+struct Acc8 {
+  double d[8];
+  uint32_t j[8];
+};
+__device__ __forceinline__ void acc_clear(Acc8 &A) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { A.d[c] = 0.0; A.j[c] = 0u; }
+}
+// D[ctx] += dt (and J[ctx] += 1 for a middle-site jump) without a runtime-indexed
+// register array: adding +0.0 to the seven other sums leaves them bit-unchanged.
+__device__ __forceinline__ void acc_add(Acc8 &A, int ctx, double dt, bool mid) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bool h = (ctx == c);
+    A.d[c] += h ? dt : 0.0;
+    A.j[c] += (h && mid) ? 1u : 0u;
+  }
+}
+
+// Path.cpp:206-301 as one 3-way merge with +inf sentinels; tie rules: left only if
+// strictly below min(mid,right), else mid only if strictly below right, else right.
+__device__ __forceinline__ void merge3(const PathRef &L, const PathRef &M, const PathRef &R,
+                                       uint64_t n, double tot_time, Acc8 &A) {
+  int ctx = (int)(4u * L.init + 2u * M.init + R.init);
+  double prev = 0.0;
+  uint32_t i = 0, j = 0, k = 0;
+  double tl = L.nj ? L.j[0] : EPV_INF;
+  double tm = M.nj ? M.j[0] : EPV_INF;
+  double tr = R.nj ? R.j[0] : EPV_INF;
+  while (i < L.nj || j < M.nj || k < R.nj) {
+    if (tl < (tm < tr ? tm : tr)) {
+      acc_add(A, ctx, tl - prev, false);
+      prev = tl; ctx ^= 4; ++i;
+      tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF;
+    } else if (tm < tr) {
+      acc_add(A, ctx, tm - prev, true);
+      prev = tm; ctx ^= 2; ++j;
+      tm = j < M.nj ? M.j[(uint64_t)j * n] : EPV_INF;
+    } else {
+      acc_add(A, ctx, tr - prev, false);
+      prev = tr; ctx ^= 1; ++k;
+      tr = k < R.nj ? R.j[(uint64_t)k * n] : EPV_INF;
+    }
+  }
+  acc_add(A, ctx, tot_time - prev, false);
+}
+
+// path_log_likelihood (SingleSiteSampler.cpp:374-391): un-logged root prior (reference
+// quirk) + sum_c J_c log(rate_c) - D_c rate_c over all branches of one triple.
+// (bl,sl),(bm,sm),(br,sr) = (buffer, site) of the left / middle / right column.
+__device__ __forceinline__ double triple_llh(const EpvDev &S, const double *s_model,
+                                             const double *s_blen, uint32_t bl, uint64_t sl,
+                                             uint32_t bm, uint64_t sm, uint32_t br,
+                                             uint64_t sr) {
+  Acc8 A;
+  acc_clear(A);
+  uint32_t rl = 0, rm = 0, rr = 0;
+  for (uint32_t b = 0; b < S.B; ++b) {
+    const PathRef L = path_ref(S, bl, b, sl), M = path_ref(S, bm, b, sm),
+                  R = path_ref(S, br, b, sr);
+    if (b == 0) { rl = L.init; rm = M.init; rr = R.init; }
+    merge3(L, M, R, S.n, s_blen[b + 1], A);
+  }
+  const double *rates = s_model, *lrates = s_model + 8, *T = s_model + 16;
+  double llh = T[2 * rl + rm] * T[2 * rm + rr];
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) s += (double)A.j[c] * lrates[c] - A.d[c] * rates[c];
+  llh += s;
+  return llh;
+}
+
+// ------------------------------------------------ forward rejection trial
+enum { TRIAL_FAIL = 0, TRIAL_OK = 1, TRIAL_OVERFLOW = 2 };
+
+// forward_sampling (EndCondSampling.cpp:466-476) for trial t of segment (node,k):
+// hold times ~ Exp(rate of the current state) = -log(1-u)/rate until T is passed.
+// `room` = jump slots left in this path; when STORE, jump times (+start_time) are
+// written to dst[0], dst[n], ...   Returns the outcome and the jump count.
+template <bool STORE>
+__device__ __forceinline__ int run_trial(uint32_t seed_lo, uint32_t seed_hi, uint32_t gsite,
+                                         uint32_t sweep, uint32_t node, uint32_t k, uint32_t t,
+                                         uint32_t a0, uint32_t end, double T, double r0,
+                                         double r1, uint32_t room, double *dst, uint64_t n,
+                                         double start_time, uint32_t &nj_out) {
+  uint32_t nj = 0, a = a0, d = 0;
+  double tau = 0.0;
+  epv_block2 blk;
+  blk.d0 = 0.0; blk.d1 = 0.0;
+  int outcome;
+  for (;;) {
+    if ((d & 1u) == 0u) blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, t, d >> 1);
+    const double u = (d & 1u) ? blk.d1 : blk.d0;
+    ++d;
+    tau += -epv_log(1.0 - u) / (a ? r1 : r0);
+    if (!(tau < T)) { outcome = (a == end) ? TRIAL_OK : TRIAL_FAIL; break; }
+    if (nj >= room) { outcome = TRIAL_OVERFLOW; break; }
+    a ^= 1u;
+    if (STORE) dst[(uint64_t)nj * n] = tau + start_time;
+    ++nj;
+  }
+  nj_out = nj;
+  return outcome;
+}
+
+// ------------------------------------------------ LDS staging of constants
+// layout (doubles): [0..19] model (rates, log_rates, T), [20 .. 20+N) branch lengths
+__device__ __forceinline__ void stage_constants(const EpvDev &S, double *s_const) {
+  const double *m = reinterpret_cast<const double *>(S.model);
+  for (uint32_t i = threadIdx.x; i < 20u + S.N; i += blockDim.x)
+    s_const[i] = (i < 20u) ? m[i] : S.blen[i - 20u];
+  __syncthreads();
+}
+
+// 2-state CTMC transition probability from the shared h = exp(-t (r0+r1))
+// (TwoStateCTMarkovModel::get_trans_prob, ContinuousTimeMarkovModel.cpp:116-125)
+__device__ __forceinline__ double gtp(double r0, double r1, double h, double denom, uint32_t a,
+                                      uint32_t b) {
+  const double prob = (a ? r0 + r1 * h : r0 * h + r1) / denom;
+  return (a == b) ? prob : 1.0 - prob;
+}
+
+// =========================================================================
+//  The Metropolis-Hastings colour-phase kernel
+// =========================================================================
+// Per-wave LDS: regA[N][64][2] doubles (per-node slot of every lane) followed by a
+// pool of `pool_entries` 32-byte segment records {p0, p1, len, trip0} handed out to the
+// lanes by a wave prefix sum (a branch with K segments uses K+1 records; the extra one
+// holds the node's q).  When the lanes of a wave together need more records than the
+// pool has, the wave runs the update in several rounds over a prefix of its lanes.
+#define EPV_MH_THREADS 256
+
+__global__ __launch_bounds__(EPV_MH_THREADS) void epv_mh_phase_kernel(
+    EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
+    uint64_t first, uint64_t last, uint32_t pool_entries, unsigned long long *counters) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  double *s_const = s_mem;                     // 20 + N doubles (padded to even)
+  const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const int lane = epv_lane();
+  const uint32_t regA_dbl = S.N * 128u;        // N * 64 lanes * 2
+  const uint32_t wave_dbl = regA_dbl + pool_entries * 4u;
+  double *regA = s_mem + const_dbl + (size_t)wave * wave_dbl;
+  double *pool = regA + regA_dbl;
+  stage_constants(S, s_const);
+  const double *s_rates = s_const;
+  const double *s_blen = s_const + 20;
+
+  // site of this lane: the t-th local site >= first whose GLOBAL index has `colour`
+  const uint64_t gfirst = S.g0 + first;
+  const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t site = s0 + 3u * tid;
+  const bool valid = site <= last;
+  const uint64_t n = S.n;
+  const uint32_t B = S.B, C = S.C;
+  const uint32_t gsite = (uint32_t)(S.g0 + site);
+
+  uint32_t selL = 0, selM = 0, selR = 0;
+  uint32_t need = 0;
+  if (valid) {
+    selL = S.sel[site - 1]; selM = S.sel[site]; selR = S.sel[site + 1];
+    for (uint32_t b = 0; b < B; ++b) {
+      const uint32_t mL = S.meta[((uint64_t)selL * B + b) * n + site - 1];
+      const uint32_t mR = S.meta[((uint64_t)selR * B + b) * n + site + 1];
+      need += (mL & 127u) + (mR & 127u) + 2u;  // K segments + 1 record for q
+    }
+  }
+
+  bool pending = valid;
+  uint32_t n_coop = 0;
+  bool accepted = false, overflowed = false;
+  while (__any(pending)) {
+    const uint32_t want = pending ? need : 0u;
+    const uint32_t incl = wave_incl_scan_u32(want);
+    const bool run = pending && incl <= pool_entries;
+    double *my = pool + (size_t)(incl - want) * 4u;  // this lane's records
+
+    // ---- 1. segments (Segment.cpp:35-79) -> records {.,.,len,trip0}
+    if (run) {
+      uint32_t off = 0;
+      for (uint32_t b = 0; b < B; ++b) {
+        const PathRef L = path_ref(S, selL, b, site - 1), R = path_ref(S, selR, b, site + 1);
+        uint32_t trip0 = 4u * L.init + R.init;
+        double prev = 0.0;
+        uint32_t i = 0, j = 0;
+        double tl = L.nj ? L.j[0] : EPV_INF, tr = R.nj ? R.j[0] : EPV_INF;
+        while (i < L.nj || j < R.nj) {
+          double *rec = my + (size_t)off * 4u;
+          // a left jump is taken only when strictly earlier than the right one;
+          // exhausted lists carry +inf so the tails fall out of the same test
+          if (tl < tr) {
+            rec[2] = tl - prev; rec[3] = epv_u2d(trip0);
+            trip0 ^= 4u; prev = tl; ++i;
+            tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF;
+          } else {
+            rec[2] = tr - prev; rec[3] = epv_u2d(trip0);
+            trip0 ^= 1u; prev = tr; ++j;
+            tr = j < R.nj ? R.j[(uint64_t)j * n] : EPV_INF;
+          }
+          ++off;
+        }
+        double *rec = my + (size_t)off * 4u;
+        rec[2] = s_blen[b + 1] - prev; rec[3] = epv_u2d(trip0);
+        off += 2u;  // last segment + the q record
+      }
+    }
+
+    // ---- 2. pruning, reverse pre-order (SingleSiteSampler.cpp:116-157)
+    if (run) {
+      uint32_t off = need;
+      for (uint32_t node = S.N - 1u; node >= 1u; --node) {
+        const uint32_t b = node - 1u;
+        const uint32_t mL = S.meta[((uint64_t)selL * B + b) * n + site - 1];
+        const uint32_t mR = S.meta[((uint64_t)selR * B + b) * n + site + 1];
+        const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
+        off -= K + 1u;
+        double q0 = 1.0, q1 = 1.0;
+        const uint32_t sub = S.subtree[node];
+        if (sub == 1u) {
+          const uint32_t mM = S.meta[((uint64_t)selM * B + b) * n + site];
+          const uint32_t leaf_state = (mM >> 7) ^ (mM & 1u);
+          q0 = leaf_state ? 0.0 : 1.0;
+          q1 = leaf_state ? 1.0 : 0.0;
+        } else {
+          for (uint32_t ch = 1u; ch < sub; ch += S.subtree[node + ch]) {
+            const double *a = regA + ((size_t)(node + ch) * 64u + lane) * 2u;
+            q0 *= a[0];
+            q1 *= a[1];
+          }
+        }
+        double *recq = my + (size_t)(off + K) * 4u;
+        recq[0] = q0; recq[1] = q1;
+        double n0 = q0, n1 = q1;
+        for (uint32_t kk = K; kk-- > 0u;) {
+          double *rec = my + (size_t)(off + kk) * 4u;
+          const double len = rec[2];
+          const uint32_t trip0 = (uint32_t)epv_d2u(rec[3]);
+          const double r0 = s_rates[trip0], r1 = s_rates[trip0 | 2u];
+          // continuous_time_trans_prob_mat (ContinuousTimeMarkovModel.cpp:143-161)
+          const double h = 1.0 / epv_exp(len * (r0 + r1));
+          const double denom = r0 + r1;
+          const double P00 = (r0 * h + r1) / denom;
+          const double P01 = 1.0 - P00;
+          const double P11 = (r0 + r1 * h) / denom;
+          const double P10 = 1.0 - P11;
+          const double a = P00 * n0 + P01 * n1;
+          const double c = P10 * n0 + P11 * n1;
+          rec[0] = a; rec[1] = c;
+          n0 = a; n1 = c;
+        }
+        double *mine = regA + ((size_t)node * 64u + lane) * 2u;
+        mine[0] = n0; mine[1] = n1;  // p.front() of the branch above `node`
+      }
+    }
+
+    // ---- 3. downward sampling (:180-255) fused with proposal_prob of the current
+    //         path (:272-339); the rejection search is wave-cooperative
+    double log_prob = 0.0, orig_proposal = 0.0;
+    bool ovf = false;
+    {
+      uint32_t off = 0;
+      const uint32_t root_state = run ? (uint32_t)(S.meta[((uint64_t)selM * B) * n + site] >> 7) : 0u;
+      for (uint32_t node = 1u; node < S.N; ++node) {
+        const uint32_t b = node - 1u;
+        uint32_t K = 0;
+        uint32_t start_state = 0;
+        PathRef cur;
+        cur.j = nullptr; cur.nj = 0; cur.init = 0;
+        if (run) {
+          const uint32_t mL = S.meta[((uint64_t)selL * B + b) * n + site - 1];
+          const uint32_t mR = S.meta[((uint64_t)selR * B + b) * n + site + 1];
+          K = (mL & 127u) + (mR & 127u) + 1u;
+          const uint32_t par = S.parent[node];
+          start_state = (par == 0u)
+                            ? root_state
+                            : (uint32_t)epv_d2u(regA[((size_t)par * 64u + lane) * 2u]);
+          cur = path_ref(S, selM, b, site);
+        }
+        double *dst_base = S.jumps + ((uint64_t)(selM ^ 1u) * B + b) * C * n + site;
+        uint32_t prev = start_state, cnt = 0;
+        double time_passed = 0.0;
+        // walk of the current path
+        uint32_t cs_start = cur.init, cs_end = cur.init, sj = 0, ej = 0;
+        double end_time = 0.0, lp = 0.0;
+        double cur_next = cur.nj ? cur.j[0] : EPV_INF;
+
+        const uint32_t kmax = wave_max_u32(K);
+        for (uint32_t k = 0; k < kmax; ++k) {
+          const bool on = run && k < K;
+          bool ok = true;
+          uint32_t sampled = 0;
+          double len = 0.0, r0 = 1.0, r1 = 1.0;
+          if (on) {
+            const double *rec = my + (size_t)(off + k) * 4u;
+            const double pk0 = rec[0], pk1 = rec[1];
+            len = rec[2];
+            const uint32_t trip0 = (uint32_t)epv_d2u(rec[3]);
+            const double nxt0 = rec[4];  // p[k+1][0], or q[0] after the last segment
+            r0 = s_rates[trip0]; r1 = s_rates[trip0 | 2u];
+            const double h = epv_exp(-len * (r0 + r1));
+            const double denom = r0 + r1;
+            // proposal: end state of the segment
+            const double PT0 = gtp(r0, r1, h, denom, prev, 0u);
+            const double p0 = PT0 * nxt0 / (prev ? pk1 : pk0);
+            const double u = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, 0u, 0u).d0;
+            sampled = (u > p0) ? 1u : 0u;
+            log_prob += (sampled == 0u) ? epv_log(p0) : epv_log(1.0 - p0);
+            if (!ovf) {
+              // first trial inline, jumps stored speculatively behind the committed ones
+              uint32_t njt;
+              const int oc = run_trial<true>(seed_lo, seed_hi, gsite, sweep, node, k, 1u, prev,
+                                             sampled, len, r0, r1, C - cnt,
+                                             dst_base + (uint64_t)cnt * n, n, time_passed, njt);
+              if (oc == TRIAL_OK) cnt += njt;
+              else if (oc == TRIAL_OVERFLOW) ovf = true;
+              else ok = false;
+            }
+            log_prob -= epv_log(gtp(r0, r1, h, denom, prev, sampled));
+            // current path: where does it stand at the end of this segment
+            end_time += len;
+            while (ej < cur.nj && cur_next < end_time) {
+              ++ej;
+              cur_next = ej < cur.nj ? cur.j[(uint64_t)ej * n] : EPV_INF;
+            }
+            if ((ej - sj) & 1u) cs_end ^= 1u;
+            const double PT0c = gtp(r0, r1, h, denom, cs_start, 0u);
+            lp -= epv_log(gtp(r0, r1, h, denom, cs_start, cs_end));
+            const double p0c = PT0c / (cs_start ? pk1 : pk0) * nxt0;
+            lp += (cs_end == 0u) ? epv_log(p0c) : epv_log(1.0 - p0c);
+            sj = ej;
+            cs_start = cs_end;
+          }
+          // wave-cooperative search for the first non-failing trial t >= 2: all 64
+          // lanes evaluate 64 consecutive trials of ONE lane's segment at a time
+          unsigned long long todo = __ballot(on && !ok);
+          while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const uint32_t l_gsite = __shfl(gsite, leader);
+            const uint32_t l_prev = __shfl(prev, leader);
+            const uint32_t l_end = __shfl(sampled, leader);
+            const uint32_t l_room = __shfl(C - cnt, leader);
+            const double l_len = shfl_f64(len, leader);
+            const double l_r0 = shfl_f64(r0, leader);
+            const double l_r1 = shfl_f64(r1, leader);
+            uint32_t tbase = 2u, tstar = 0u;
+            for (;;) {
+              uint32_t njt;
+              const int oc = run_trial<false>(seed_lo, seed_hi, l_gsite, sweep, node, k,
+                                              tbase + (uint32_t)lane, l_prev, l_end, l_len, l_r0,
+                                              l_r1, l_room, nullptr, n, 0.0, njt);
+              const unsigned long long hit = __ballot(oc != TRIAL_FAIL);
+              if (hit) { tstar = tbase + (uint32_t)(__ffsll((long long)hit) - 1); break; }
+              tbase += 64u;
+            }
+            if (lane == leader) {
+              uint32_t njt;
+              const int oc = run_trial<true>(seed_lo, seed_hi, gsite, sweep, node, k, tstar, prev,
+                                             sampled, len, r0, r1, C - cnt,
+                                             dst_base + (uint64_t)cnt * n, n, time_passed, njt);
+              if (oc == TRIAL_OK) cnt += njt;
+              else ovf = true;
+              ++n_coop;
+            }
+          }
+          if (on) {
+            time_passed += len;
+            prev = sampled;
+          }
+        }
+        if (run) {
+          if (ovf) cnt = (start_state ^ prev) & 1u;  // keep parity for the children
+          S.meta[((uint64_t)(selM ^ 1u) * B + b) * n + site] = (uint8_t)((start_state << 7) | cnt);
+          regA[((size_t)node * 64u + lane) * 2u] = epv_u2d((uint64_t)prev);  // proposal end state
+          orig_proposal += lp;
+          off += K + 1u;
+        }
+      }
+    }
+
+    // ---- 4. acceptance (log_accept_rate :396-433, Metropolis_Hastings_site :510-533)
+    if (run) {
+      double llh_l = S.tri[site - 1];
+      double llh_m = S.tri[site];
+      double llh_r = S.tri[site + 1];
+      double llr = orig_proposal - log_prob;
+      const double llh_l_orig = llh_l, llh_r_orig = llh_r;
+      if (!ovf) {
+        const uint32_t selP = selM ^ 1u;
+        const uint64_t g = S.g0 + site;
+        if (g > 1u)
+          llh_l = triple_llh(S, s_const, s_blen, S.sel[site - 2], site - 2, selL, site - 1, selP, site);
+        llh_m = triple_llh(S, s_const, s_blen, selL, site - 1, selP, site, selR, site + 1);
+        if (g < S.n_global - 2u)
+          llh_r = triple_llh(S, s_const, s_blen, selP, site, selR, site + 1, S.sel[site + 2], site + 2);
+      }
+      llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
+      const double u = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, 0u, 0u, 0u, 0u).d0;
+      bool acc = (llr >= 0.0) || (u < epv_exp(llr));
+      if (ovf) { acc = false; overflowed = true; }
+      if (acc) {
+        S.sel[site] = (uint8_t)(selM ^ 1u);
+        S.tri[site - 1] = llh_l;
+        S.tri[site] = llh_m;
+        S.tri[site + 1] = llh_r;
+        accepted = true;
+      }
+      pending = false;
+    }
+  }
+
+  // ---- counters: one atomic per wave and kind
+  const unsigned long long am = __ballot(accepted), om = __ballot(overflowed);
+  uint32_t coop = n_coop;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) coop += __shfl_xor(coop, d);
+  if (lane == 0) {
+    if (am) atomicAdd(&counters[EPV_CNT_ACCEPT], (unsigned long long)__popcll(am));
+    if (om) atomicAdd(&counters[EPV_CNT_OVERFLOW], (unsigned long long)__popcll(om));
+    if (coop) atomicAdd(&counters[EPV_CNT_COOP], (unsigned long long)coop);
+  }
+}
+
+// =========================================================================
+//  reset: tri[s] = path_log_likelihood(s-1, s, s+1) for every local interior site
+// =========================================================================
+__global__ __launch_bounds__(256) void epv_reset_kernel(EpvDev S) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  stage_constants(S, s_mem);
+  const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= S.n) return;
+  double v = 0.0;
+  if (site >= 1 && site + 1 < S.n)
+    v = triple_llh(S, s_mem, s_mem + 20, S.sel[site - 1], site - 1, S.sel[site], site,
+                   S.sel[site + 1], site + 1);
+  S.tri[site] = v;
+}
+
+// =========================================================================
+//  sufficient statistics: per-branch J[8], D[8] over the triples centred at local
+//  sites [first,last], reduced in the canonical balanced-binary-tree order over the
+//  local site index (lane butterfly -> 4 waves through LDS -> block partials ->
+//  epv_tree_reduce_kernel levels).  partial layout: [block][b][16] (J then D).
+// =========================================================================
+__device__ __forceinline__ double block_tree_sum_256(double v, double *s_red) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v = v + shfl_xor_f64(v, d);
+  const uint32_t wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (epv_lane() == 0) s_red[wave] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t first,
+                                                           uint64_t last, double *partial) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  __shared__ double s_red[4];
+  stage_constants(S, s_mem);
+  const double *s_blen = s_mem + 20;
+  const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = site >= first && site <= last && site >= 1 && site + 1 < S.n;
+  uint32_t sl = 0, sm = 0, sr = 0;
+  if (on) { sl = S.sel[site - 1]; sm = S.sel[site]; sr = S.sel[site + 1]; }
+  for (uint32_t b = 0; b < S.B; ++b) {
+    Acc8 A;
+    acc_clear(A);
+    if (on) {
+      const PathRef L = path_ref(S, sl, b, site - 1), M = path_ref(S, sm, b, site),
+                    R = path_ref(S, sr, b, site + 1);
+      merge3(L, M, R, S.n, s_blen[b + 1], A);
+    }
+    double *out = partial + ((uint64_t)blockIdx.x * S.B + b) * 16u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double js = block_tree_sum_256((double)A.j[c], s_red);
+      const double ds = block_tree_sum_256(A.d[c], s_red);
+      if (threadIdx.x == 0) { out[c] = js; out[8 + c] = ds; }
+    }
+  }
+}
+
+// one level of the tree: in[m][V] -> out[ceil(m/256)][V], each block sums 256
+// consecutive (aligned) entries of every value column in balanced order
+__global__ __launch_bounds__(256) void epv_tree_reduce_kernel(const double *in, uint64_t m,
+                                                              uint32_t V, double *out) {
+  __shared__ double s_red[4];
+  const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  for (uint32_t v = 0; v < V; ++v) {
+    const double x = idx < m ? in[idx * V + v] : 0.0;
+    const double s = block_tree_sum_256(x, s_red);
+    if (threadIdx.x == 0) out[(uint64_t)blockIdx.x * V + v] = s;
+  }
+}
+
+// acc[i] += one[i]  (J_all_sites += J_one_site, SingleSiteSampler.cpp:582-586)
+__global__ void epv_accumulate_kernel(double *acc, const double *one, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) acc[i] += one[i];
+}
+
+// =========================================================================
+//  scale_jump_times (ParamEstimation.cpp:369-380): jumps *= scale[b]
+// =========================================================================
+__global__ __launch_bounds__(256) void epv_scale_kernel(EpvDev S, const double *scale) {
+  const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= S.n) return;
+  const uint32_t buf = S.sel[site];
+  for (uint32_t b = 0; b < S.B; ++b) {
+    const uint64_t plane = (uint64_t)buf * S.B + b;
+    const uint32_t nj = S.meta[plane * S.n + site] & 127u;
+    double *j = S.jumps + plane * S.C * S.n + site;
+    const double sc = scale[b + 1];
+    for (uint32_t k = 0; k < nj; ++k) j[(uint64_t)k * S.n] *= sc;
+  }
+}
+
+// =========================================================================
+//  layout conversion between the ABI's node-major CSR form and the device SoA form
+// =========================================================================
+__global__ __launch_bounds__(256) void epv_scatter_kernel(EpvDev S, const uint8_t *init,
+                                                          const uint64_t *offsets,
+                                                          const double *jumps_csr) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (uint64_t)S.B * S.n) return;
+  const uint64_t b = e / S.n, site = e % S.n;
+  const uint64_t o = offsets[e];
+  const uint32_t cnt = (uint32_t)(offsets[e + 1] - o);
+  S.meta[b * S.n + site] = (uint8_t)((init[e] ? 0x80u : 0u) | cnt);  // buffer 0
+  double *j = S.jumps + b * S.C * S.n + site;
+  for (uint32_t k = 0; k < cnt; ++k) j[(uint64_t)k * S.n] = jumps_csr[o + k];
+  if (b == 0) { S.sel[site] = 0; S.tri[site] = 0.0; }
+}
+
+// counts[e] = number of jumps of the CURRENT path of entry e; init_out[e] likewise
+__global__ __launch_bounds__(256) void epv_count_kernel(EpvDev S, uint8_t *init_out,
+                                                        uint64_t *counts) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (uint64_t)S.B * S.n) return;
+  const uint64_t b = e / S.n, site = e % S.n;
+  const uint8_t m = S.meta[((uint64_t)S.sel[site] * S.B + b) * S.n + site];
+  init_out[e] = m >> 7;
+  counts[e] = m & 127u;
+}
+
+__global__ __launch_bounds__(256) void epv_gather_kernel(EpvDev S, const uint64_t *offsets,
+                                                         double *jumps_csr) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (uint64_t)S.B * S.n) return;
+  const uint64_t b = e / S.n, site = e % S.n;
+  const uint64_t plane = (uint64_t)S.sel[site] * S.B + b;
+  const uint32_t cnt = S.meta[plane * S.n + site] & 127u;
+  const double *j = S.jumps + plane * S.C * S.n + site;
+  const uint64_t o = offsets[e];
+  for (uint32_t k = 0; k < cnt; ++k) jumps_csr[o + k] = j[(uint64_t)k * S.n];
+}
+
+// ------------------------------------------------ halo columns (site-sharded runs)
+// packed column = [B bytes meta (current path)] padded to 8, [B*C doubles jumps],
+// [3 doubles tri(s-1), tri(s), tri(s+1)]
+__device__ __forceinline__ uint64_t epv_col_bytes(uint32_t B, uint32_t C) {
+  return (((uint64_t)B + 7u) & ~7ull) + ((uint64_t)B * C + 3u) * 8u;
+}
+__global__ void epv_pack_columns_kernel(EpvDev S, uint64_t first, uint64_t count,
+                                        uint8_t *packed) {
+  const uint64_t c = blockIdx.x;
+  if (c >= count) return;
+  const uint64_t site = first + c;
+  const uint64_t cb = epv_col_bytes(S.B, S.C);
+  uint8_t *col = packed + c * cb;
+  double *dj = reinterpret_cast<double *>(col + (((uint64_t)S.B + 7u) & ~7ull));
+  const uint32_t buf = S.sel[site];
+  for (uint32_t i = threadIdx.x; i < S.B * S.C; i += blockDim.x) {
+    const uint32_t b = i / S.C, k = i % S.C;
+    const uint64_t plane = (uint64_t)buf * S.B + b;
+    const uint32_t nj = S.meta[plane * S.n + site] & 127u;
+    dj[i] = k < nj ? S.jumps[(plane * S.C + k) * S.n + site] : 0.0;
+  }
+  for (uint32_t b = threadIdx.x; b < S.B; b += blockDim.x)
+    col[b] = S.meta[((uint64_t)buf * S.B + b) * S.n + site];
+  if (threadIdx.x < 3) {
+    const int64_t s = (int64_t)site + (int64_t)threadIdx.x - 1;
+    dj[(uint64_t)S.B * S.C + threadIdx.x] = (s >= 0 && (uint64_t)s < S.n) ? S.tri[s] : 0.0;
+  }
+}
+__global__ void epv_unpack_columns_kernel(EpvDev S, uint64_t first, uint64_t count,
+                                          const uint8_t *packed) {
+  const uint64_t c = blockIdx.x;
+  if (c >= count) return;
+  const uint64_t site = first + c;
+  const uint64_t cb = epv_col_bytes(S.B, S.C);
+  const uint8_t *col = packed + c * cb;
+  const double *dj = reinterpret_cast<const double *>(col + (((uint64_t)S.B + 7u) & ~7ull));
+  const uint32_t buf = S.sel[site];  // overwrite the current buffer in place
+  for (uint32_t i = threadIdx.x; i < S.B * S.C; i += blockDim.x) {
+    const uint32_t b = i / S.C, k = i % S.C;
+    const uint32_t nj = col[b] & 127u;
+    if (k < nj) S.jumps[(((uint64_t)buf * S.B + b) * S.C + k) * S.n + site] = dj[i];
+  }
+  for (uint32_t b = threadIdx.x; b < S.B; b += blockDim.x)
+    S.meta[((uint64_t)buf * S.B + b) * S.n + site] = col[b];
+  if (threadIdx.x < 3) {
+    const int64_t s = (int64_t)site + (int64_t)threadIdx.x - 1;
+    if (s >= 0 && (uint64_t)s < S.n) S.tri[s] = dj[(uint64_t)S.B * S.C + threadIdx.x];
+  }
+}
+
+#endif

@@ -1,0 +1,247 @@
+"""ctypes binding of libepievo_mi355x.so (the C ABI of include/epievo_mi355x.h) and a
+Python mirror of the reference's SingleSiteSampler interface on top of it
+(/root/reference/src/libepievo/SingleSiteSampler.hpp:35-81: ctor(burn_in, batch),
+reset(model, paths), run_mcmc(...) -> J, D, acc_rate).
+
+There is no CPU fallback: if the HIP library is missing or no GPU can be opened,
+construction raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+from .host import FlatPaths
+
+_lib = None
+
+EPV_OK, EPV_ERR_ARG, EPV_ERR_HIP, EPV_ERR_CAPACITY, EPV_ERR_STATE = 0, 1, 2, 3, 4
+
+
+class EpvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("epv error %d: %s" % (code, msg))
+        self.code = code
+
+
+class CapacityError(EpvError):
+    pass
+
+
+class _Counters(C.Structure):
+    _fields_ = [("n_overflow", C.c_uint64), ("n_coop_tasks", C.c_uint64),
+                ("n_sweeps", C.c_uint64), ("reserved", C.c_uint64)]
+
+
+ABI_SYMBOLS = [
+    "epv_create", "epv_destroy", "epv_last_error", "epv_set_tree", "epv_set_model",
+    "epv_upload_paths", "epv_set_global_length", "epv_set_update_range", "epv_reset", "epv_sweep",
+    "epv_sweep_phase", "epv_run_mcmc", "epv_get_sufficient_statistics", "epv_scale_jump_times",
+    "epv_paths_total_jumps", "epv_download_paths", "epv_get_tri_llh", "epv_column_bytes",
+    "epv_get_columns", "epv_put_columns", "epv_get_counters", "epv_kernel_time_ms",
+    "epv_set_timing",
+]
+
+
+def lib():
+    """Load the HIP library; raise (never fall back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        path = _build.HIP_SO
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` (hipcc --offload-arch=gfx950)" % path)
+        L = C.CDLL(path)
+        dp, u8p, u32p, u64p, vp = (C.POINTER(C.c_double), C.POINTER(C.c_uint8),
+                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p)
+        L.epv_create.argtypes = [C.c_int]
+        L.epv_create.restype = vp
+        L.epv_destroy.argtypes = [vp]
+        L.epv_destroy.restype = None
+        L.epv_last_error.argtypes = [vp]
+        L.epv_last_error.restype = C.c_char_p
+        L.epv_set_tree.argtypes = [vp, C.c_int, u32p, u32p, dp]
+        L.epv_set_model.argtypes = [vp, dp, dp]
+        L.epv_upload_paths.argtypes = [vp, C.c_uint64, u8p, u64p, dp, C.c_uint32, C.c_uint64]
+        L.epv_set_global_length.argtypes = [vp, C.c_uint64]
+        L.epv_set_update_range.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.epv_reset.argtypes = [vp]
+        L.epv_sweep.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, u64p]
+        L.epv_sweep_phase.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint32, u64p]
+        L.epv_run_mcmc.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, dp, dp, u64p]
+        L.epv_get_sufficient_statistics.argtypes = [vp, dp, dp]
+        L.epv_scale_jump_times.argtypes = [vp, dp]
+        L.epv_paths_total_jumps.argtypes = [vp, u64p]
+        L.epv_download_paths.argtypes = [vp, u8p, u64p, dp]
+        L.epv_get_tri_llh.argtypes = [vp, dp]
+        L.epv_column_bytes.argtypes = [vp]
+        L.epv_column_bytes.restype = C.c_uint64
+        L.epv_get_columns.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
+        L.epv_put_columns.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
+        L.epv_get_counters.argtypes = [vp, C.POINTER(_Counters)]
+        L.epv_kernel_time_ms.argtypes = [vp, dp, u64p]
+        L.epv_set_timing.argtypes = [vp, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class DeviceSampler:
+    """One context = one GPU.  Thin, explicit face of the C ABI."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = self.L.epv_create(device)
+        if not self.h:
+            raise RuntimeError("epv_create(%d) failed: no usable HIP device (this build has no "
+                               "CPU fallback)" % device)
+        self.n_sites = self.n_nodes = self.B = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.epv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != EPV_OK:
+            msg = self.L.epv_last_error(self.h).decode()
+            raise (CapacityError if rc == EPV_ERR_CAPACITY else EpvError)(rc, msg)
+
+    def set_tree(self, tree):
+        self.n_nodes, self.B = tree.n_nodes, tree.n_nodes - 1
+        self._ck(self.L.epv_set_tree(self.h, tree.n_nodes, _p(tree.parent_ids, C.c_uint32),
+                                     _p(tree.subtree_sizes, C.c_uint32),
+                                     _p(tree.branches, C.c_double)))
+
+    def set_model(self, model):
+        self._ck(self.L.epv_set_model(self.h, _p(model.rates, C.c_double), _p(model.T, C.c_double)))
+
+    def upload_paths(self, fp, capacity=0, global_site_offset=0, n_global=None):
+        jumps = fp.jumps if len(fp.jumps) else np.zeros(1)
+        self.n_sites = fp.n_sites
+        self._ck(self.L.epv_upload_paths(self.h, fp.n_sites, _p(fp.init, C.c_uint8),
+                                         _p(fp.offsets, C.c_uint64), _p(jumps, C.c_double),
+                                         capacity, global_site_offset))
+        if n_global is not None:
+            self._ck(self.L.epv_set_global_length(self.h, n_global))
+
+    def set_update_range(self, first, last):
+        self._ck(self.L.epv_set_update_range(self.h, first, last))
+
+    def reset(self):
+        self._ck(self.L.epv_reset(self.h))
+
+    def sweep(self, n_sweeps, seed, sweep_base=0):
+        nacc = C.c_uint64(0)
+        self._ck(self.L.epv_sweep(self.h, n_sweeps, seed, sweep_base, C.byref(nacc)))
+        return int(nacc.value)
+
+    def sweep_phase(self, colour, seed, sweep):
+        nacc = C.c_uint64(0)
+        self._ck(self.L.epv_sweep_phase(self.h, colour, seed, sweep, C.byref(nacc)))
+        return int(nacc.value)
+
+    def run_mcmc(self, burn_in, batch, seed, sweep_base=0):
+        J, D = np.zeros(self.B * 8), np.zeros(self.B * 8)
+        nacc = C.c_uint64(0)
+        self._ck(self.L.epv_run_mcmc(self.h, burn_in, batch, seed, sweep_base, _p(J, C.c_double),
+                                     _p(D, C.c_double), C.byref(nacc)))
+        return J, D, int(nacc.value)
+
+    def suffstats(self):
+        J, D = np.zeros(self.B * 8), np.zeros(self.B * 8)
+        self._ck(self.L.epv_get_sufficient_statistics(self.h, _p(J, C.c_double), _p(D, C.c_double)))
+        return J, D
+
+    def scale_jump_times(self, new_branches):
+        nb = np.ascontiguousarray(new_branches, dtype=np.float64)
+        self._ck(self.L.epv_scale_jump_times(self.h, _p(nb, C.c_double)))
+
+    def paths(self):
+        tot = C.c_uint64(0)
+        self._ck(self.L.epv_paths_total_jumps(self.h, C.byref(tot)))
+        init = np.zeros(self.B * self.n_sites, np.uint8)
+        off = np.zeros(self.B * self.n_sites + 1, np.uint64)
+        jumps = np.zeros(max(tot.value, 1))
+        self._ck(self.L.epv_download_paths(self.h, _p(init, C.c_uint8), _p(off, C.c_uint64),
+                                           _p(jumps, C.c_double)))
+        return FlatPaths(self.n_sites, self.n_nodes, init, off, jumps[:tot.value])
+
+    def tri_llh(self):
+        out = np.zeros(self.n_sites)
+        self._ck(self.L.epv_get_tri_llh(self.h, _p(out, C.c_double)))
+        return out
+
+    def column_bytes(self):
+        return int(self.L.epv_column_bytes(self.h))
+
+    def get_columns(self, first, count):
+        buf = np.zeros(count * self.column_bytes(), np.uint8)
+        self._ck(self.L.epv_get_columns(self.h, first, count, buf.ctypes.data_as(C.c_void_p)))
+        return buf
+
+    def put_columns(self, first, count, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self._ck(self.L.epv_put_columns(self.h, first, count, buf.ctypes.data_as(C.c_void_p)))
+
+    def counters(self):
+        c = _Counters()
+        self._ck(self.L.epv_get_counters(self.h, C.byref(c)))
+        return {"overflow": c.n_overflow, "coop_tasks": c.n_coop_tasks, "sweeps": c.n_sweeps}
+
+    def set_timing(self, on):
+        self._ck(self.L.epv_set_timing(self.h, int(on)))
+
+    def kernel_time_ms(self):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._ck(self.L.epv_kernel_time_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, int(n.value)
+
+
+class SingleSiteSampler:
+    """Mirror of the reference class (SingleSiteSampler.hpp:35-81).
+
+    mcmc = SingleSiteSampler(burn_in, batch); mcmc.reset(model, tree, paths);
+    J, D, acc_rate = mcmc.run_mcmc(seed, em_iter)      # paths stay on the GPU
+    paths = mcmc.paths()                               # download when needed
+    The reference threads one std::mt19937 through every call; here the random
+    stream is the counter-based (seed, sweep) pair, so the caller passes the seed and
+    the index of the EM iteration (sweep numbers never repeat across iterations)."""
+
+    def __init__(self, n_burn_in, n_batch, device=0, capacity=0):
+        self.burn_in, self.batch = int(n_burn_in), int(n_batch)
+        self.SAMPLE_ROOT = False  # hard-wired false in the reference (SingleSiteSampler.cpp:441)
+        self.capacity = capacity
+        self.dev = DeviceSampler(device)
+        self._uploaded = False
+
+    def reset(self, model, tree, paths=None):
+        self.dev.set_tree(tree)
+        self.dev.set_model(model)
+        if paths is not None:
+            self.dev.upload_paths(paths, self.capacity)
+            self._uploaded = True
+        if not self._uploaded:
+            raise EpvError(EPV_ERR_STATE, "reset() needs paths the first time")
+        self.dev.reset()
+
+    def run_mcmc(self, seed, em_iter=0):
+        base = em_iter * (self.burn_in + self.batch)
+        J, D, nacc = self.dev.run_mcmc(self.burn_in, self.batch, seed, base)
+        acc_rate = nacc / float(self.batch * (self.dev.n_sites - 2))
+        return J, D, acc_rate
+
+    def sweeps(self, n, seed, sweep_base=0):
+        return self.dev.sweep(n, seed, sweep_base)
+
+    def scale_jump_times(self, new_branches):
+        self.dev.scale_jump_times(new_branches)
+
+    def paths(self):
+        return self.dev.paths()

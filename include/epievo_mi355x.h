@@ -1,0 +1,149 @@
+/* epievo_mi355x.h -- C ABI of the MI355X (gfx950) implementation of epievo's MCEM
+ * inner loop: the per-site Metropolis-Hastings end-conditioned path sampler.
+ *
+ * The reference has no FFI; its boundary for this path is the C++ class
+ * SingleSiteSampler (/root/reference/src/libepievo/SingleSiteSampler.hpp:35-81) plus
+ * two free functions of ParamEstimation.hpp.  Each entry point below names the
+ * reference interface it replaces.  The C++ wrapper epv::SingleSiteSampler
+ * (epievo_amd/csrc/host/epv_sampler.hpp) keeps the reference's names and argument
+ * meaning on top of this ABI; INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all buffers are caller-owned HOST memory unless a
+ *    name ends in _dev (then it is a device pointer on the context's GPU);
+ *  - every call returns 0 on success or a non-zero EPV_ERR_* code; the message is
+ *    available from epv_last_error(ctx).  No exception crosses the boundary;
+ *  - one context per GPU, calls on one context are serialised by the caller (the
+ *    reference class is single-threaded and not re-entrant either);
+ *  - paths are passed "node-major flat": for node b = 1..n_nodes-1 and site s the
+ *    entry index is e = (b-1)*n_sites + s; init_state[e] is Path::init_state, the
+ *    jumps are jumps[offsets[e] .. offsets[e+1]) (Path::jumps, ascending, absolute
+ *    times in (0, branch length)).  Node 0 (the root) has no path, as in the
+ *    reference where paths[site][0] is a dummy (epievo_est_params_histories.cpp:186-192);
+ *  - J and D are per-branch sufficient statistics laid out [(b-1)*8 + ctx] with
+ *    ctx = 4*left + 2*mid + right (epievo_utils.hpp:85-88).
+ */
+#ifndef EPIEVO_MI355X_H
+#define EPIEVO_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct epv_ctx epv_ctx;
+
+enum {
+  EPV_OK = 0,
+  EPV_ERR_ARG = 1,      /* bad argument / call order */
+  EPV_ERR_HIP = 2,      /* a HIP runtime call failed (no device, OOM, ...) */
+  EPV_ERR_CAPACITY = 3, /* a proposed path needed more than `capacity` jumps */
+  EPV_ERR_STATE = 4     /* paths/model/tree not set */
+};
+
+/* counters returned by epv_get_counters */
+typedef struct {
+  uint64_t n_overflow;   /* proposals rejected because a branch exceeded `capacity` jumps */
+  uint64_t n_coop_tasks; /* rejection tasks resolved by the wave-cooperative search */
+  uint64_t n_sweeps;     /* colour-complete sweeps executed since create */
+  uint64_t reserved;
+} epv_counters;
+
+/* Create a context on HIP device `device_id`.  Returns NULL when the device cannot be
+ * initialised (the product has no CPU fallback).  Replaces
+ * SingleSiteSampler::SingleSiteSampler (SingleSiteSampler.cpp:439-447). */
+epv_ctx *epv_create(int device_id);
+void epv_destroy(epv_ctx *ctx);
+const char *epv_last_error(const epv_ctx *ctx);
+
+/* Tree in pre-order array form = the fields of TreeHelper (TreeHelper.hpp:47-51):
+ * subtree_sizes, parent_ids, branches (branches[0] = 0, the root). */
+int epv_set_tree(epv_ctx *ctx, int n_nodes, const uint32_t *parent_ids,
+                 const uint32_t *subtree_sizes, const double *branches);
+
+/* Model = the two members of EpiEvoModel the sampler reads (EpiEvoModel.hpp:37-41):
+ * triplet_rates[8] and the horizontal transition matrix T (row-major 2x2).
+ * log(rate) is taken here on the host with libm, as reset() does
+ * (SingleSiteSampler.cpp:464-468). */
+int epv_set_model(epv_ctx *ctx, const double *triplet_rates, const double *T);
+
+/* Upload all paths (replaces handing `vector<vector<Path>>&` to reset()).
+ * `capacity` is the fixed number of jump slots kept per (site, branch) on the device
+ * (1..127); 0 picks max(16, 2*max_jumps_in_input + 8).  A proposal that would need
+ * more is rejected and counted (epv_counters.n_overflow) and the MCMC call that saw it
+ * returns EPV_ERR_CAPACITY after completing -- re-upload with a larger capacity.
+ * `global_site_offset`: index of local site 0 in the whole genome (0 on one GPU);
+ * it keys the RNG and the 3-colouring so that sharded runs reproduce unsharded ones. */
+int epv_upload_paths(epv_ctx *ctx, uint64_t n_sites, const uint8_t *init_state,
+                     const uint64_t *offsets, const double *jumps, uint32_t capacity,
+                     uint64_t global_site_offset);
+
+/* Site-sharded runs only: total genome length (default: global_site_offset + n_sites),
+ * so that the two special cases at the genome ends (SingleSiteSampler.cpp:422,427) are
+ * decided on global indices. */
+int epv_set_global_length(epv_ctx *ctx, uint64_t n_global);
+
+/* Restrict MH updates to local sites [first, last] (inclusive); default [1, n_sites-2].
+ * Sites outside are read-only halo/boundary columns. */
+int epv_set_update_range(epv_ctx *ctx, uint64_t first, uint64_t last);
+
+/* SingleSiteSampler::reset (SingleSiteSampler.cpp:449-475): cache the complete-data
+ * log-likelihood of every interior triple. */
+int epv_reset(epv_ctx *ctx);
+
+/* n_sweeps x single_iteration (SingleSiteSampler.cpp:538-548) under the 3-colour
+ * schedule; this is also the loop epievo_sim_pairwise.cpp:267-273 spells out by hand.
+ * Sweep w uses RNG sweep index sweep_base + w.  n_accepted may be NULL. */
+int epv_sweep(epv_ctx *ctx, uint64_t n_sweeps, uint64_t seed, uint32_t sweep_base,
+              uint64_t *n_accepted);
+
+/* One colour phase (colour = global_site % 3) of sweep `sweep`; used by multi-GPU
+ * drivers that exchange halo columns between phases. */
+int epv_sweep_phase(epv_ctx *ctx, int colour, uint64_t seed, uint32_t sweep,
+                    uint64_t *n_accepted);
+
+/* SingleSiteSampler::run_mcmc (SingleSiteSampler.cpp:550-598): burn_in sweeps, then
+ * batch x {sweep; get_sufficient_statistics; accumulate}.  J/D ((n_nodes-1)*8 doubles
+ * each) return the batch AVERAGES as the reference does; n_accepted counts the batch
+ * sweeps only (acc_rate = n_accepted / (batch*(n_sites-2))). */
+int epv_run_mcmc(epv_ctx *ctx, uint64_t burn_in, uint64_t batch, uint64_t seed,
+                 uint32_t sweep_base, double *J, double *D, uint64_t *n_accepted);
+
+/* get_sufficient_statistics, per-branch overload (ParamEstimation.cpp:92-114), over
+ * the update range's triples, reduced in the canonical binary-tree order. */
+int epv_get_sufficient_statistics(epv_ctx *ctx, double *J, double *D);
+
+/* scale_jump_times (ParamEstimation.cpp:369-380): jumps *= new/old per branch. */
+int epv_scale_jump_times(epv_ctx *ctx, const double *new_branches);
+
+/* Download the current paths (what the EM driver writes out each iteration,
+ * epievo_est_params_histories.cpp:280-283).  Call epv_paths_total_jumps first to size
+ * `jumps`; offsets has (n_nodes-1)*n_sites + 1 entries. */
+int epv_paths_total_jumps(epv_ctx *ctx, uint64_t *total);
+int epv_download_paths(epv_ctx *ctx, uint8_t *init_state, uint64_t *offsets, double *jumps);
+
+/* the cached triple log-likelihoods (private member tri_llh of the reference class);
+ * exposed for parity tests.  out has n_sites entries. */
+int epv_get_tri_llh(epv_ctx *ctx, double *out);
+
+/* Halo exchange for site-sharded runs: copy `count` whole site columns (all branches)
+ * starting at local site `first` to / from a packed host buffer of
+ * epv_column_bytes(ctx) bytes per column. */
+uint64_t epv_column_bytes(const epv_ctx *ctx);
+int epv_get_columns(epv_ctx *ctx, uint64_t first, uint64_t count, void *packed);
+int epv_put_columns(epv_ctx *ctx, uint64_t first, uint64_t count, const void *packed);
+
+int epv_get_counters(epv_ctx *ctx, epv_counters *out);
+
+/* Timing hook for bench.py: average duration (ms) of the colour-phase kernel launches
+ * issued since the last call, measured with HIP events on the context's stream, and
+ * how many launches that covers. */
+int epv_kernel_time_ms(epv_ctx *ctx, double *avg_ms, uint64_t *n_launches);
+int epv_set_timing(epv_ctx *ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

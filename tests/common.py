@@ -1,0 +1,48 @@
+"""Shared helpers for the test-suite (inputs, configurations)."""
+import os
+
+import numpy as np
+
+from epievo_amd import host
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+# the reference's test/test.param and test/tree.nwk, restated as data (2 + 1 lines)
+TEST_PARAM_TEXT = "stationary\t0.844912\t0.893359\nbaseline\t-0.8\t-1.8\n"
+TREE_NWK_TEXT = "((C:0.03,D:0.06)E:0.02,F:0.1)G:0.0;\n"
+
+
+def _tmp(name, text):
+    import tempfile
+    d = os.path.join(tempfile.gettempdir(), "epv_tests_%d" % os.getuid())
+    os.makedirs(d, exist_ok=True)
+    p = os.path.join(d, name)
+    with open(p, "w") as f:
+        f.write(text)
+    return p
+
+
+def test_model():
+    return host.Model.read(_tmp("test.param", TEST_PARAM_TEXT), scale=True)
+
+
+def tree_nwk():
+    return host.Tree.read(_tmp("tree.nwk", TREE_NWK_TEXT))
+
+
+def config(name):
+    """(tree, default n) for the named BASELINE configuration"""
+    if name == "tree":
+        return tree_nwk()
+    if name == "pair":
+        return host.Tree.single_branch(1.0)
+    if name == "bal16":
+        return host.Tree.balanced(16, 0.05)
+    raise KeyError(name)
+
+
+def simulate(name, n, seed=42):
+    m = test_model()
+    t = config(name)
+    return m, t, host.simulate(m, t, n, seed)

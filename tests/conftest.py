@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def test_model():
+    """test/test.param of the reference (stationary 0.844912 0.893359 / baseline -0.8 -1.8)
+    scaled to unit rate; values are the reference's own (golden/model.json pins them)."""
+    from common import test_model as tm
+    return tm()
+
+
+@pytest.fixture(scope="session")
+def tree_nwk():
+    from common import tree_nwk as t
+    return t()
