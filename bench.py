@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- site-branch path resamples/s of the MCEM inner loop on MI355X.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): the 4-branch
+test/tree.nwk tree, n = 1e6 sites per GPU, test/test.param scaled to unit rate, synthetic
+histories forward-simulated on the host, true history as the initial MCMC state.
+One "step" = the E-step of one EM iteration exactly as epievo_est_params_histories
+drives it with -L 10 -B 50: reset() + run_mcmc() = 60 three-colour sweeps, with the
+per-branch sufficient statistics J/D reduced after each of the 50 batch sweeps.
+    resamples per step = (L + B) * (n_owned_sites) * (n_nodes - 1)
+Inputs are resident in HBM before the timed region; file IO, upload/download and the
+O(8) host M-step are outside it.
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 it is launched by torch.distributed.run (one rank per GPU, RCCL): the genome
+of N * n sites is cut into contiguous shards with 2-site halos; boundary columns are
+exchanged after every colour phase and J/D are all-reduced once per step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+N_SITES = 1000000
+BURN_IN, BATCH = 10, 50
+SEED = 42
+
+
+def algorithmic_bytes_per_resample(kbar, n_branches):
+    """each path read once and written once per sweep in the SoA
+    layout {1 B state+count, 4 B offset/count, 8 B per jump} + tri_llh 8 B read + 8 B
+    write per site."""
+    return 2.0 * (1.0 + 4.0 + 8.0 * kbar) + 16.0 / n_branches
+
+
+def cpu_baseline(model, tree, fp, budget_s=20.0):
+    """The reference's own CPU path (oracle/_ref, the unmodified libepievo built in the
+    authoring container) or, when that .so is absent, the bit-identical C restatement
+    (oracle rung A), on ONE core (the reference is single-threaded), on a bounded sample
+    of the same workload: the first n_s sites, a few sequential sweeps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    n_s = 200000
+    sub = fp.slice_sites(0, n_s)
+    if orc.have_ref():
+        eng, kind = orc.Reference(tree, model, sub, seed=SEED), "reference"
+        eng.reset(0, 1)
+        sweep = lambda: eng.sweeps(1)
+    else:
+        eng, kind = orc.Oracle(tree, model, sub, "A", seed=SEED), "port"
+        eng.reset()
+        sweep = lambda: eng.sweep(0)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        sweep()
+        k += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or k >= 40:
+            break
+    rs = k * (n_s - 2) * (tree.n_nodes - 1)
+    return {"value": rs / el, "unit": "site-branch resamples/s", "cores": 1, "kind": kind,
+            "sample": "%d sequential sweeps over the first %d sites of the same workload "
+                      "(%.1f s, run_mcmc region only)" % (k, n_s, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sites", type=int, default=N_SITES, help="sites per GPU")
+    ap.add_argument("--config", default="tree", choices=["tree", "pair", "bal16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py "
+                     "--gpus %d ..." % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    from epievo_amd import host
+    from epievo_amd.parallel import ShardedSampler, TorchComm, NullComm
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import test_model, config
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = TorchComm(dist, torch.device("cuda", local_rank))
+    else:
+        comm = NullComm()
+
+    model = test_model()
+    tree = config(args.config)
+    n_local = args.sites
+    n_global = n_local * world
+    # every rank simulates its own shard (+ halos come from the neighbours' edges)
+    fp_own = host.simulate(model, tree, n_local, SEED + rank)
+    kbar = len(fp_own.jumps) / float(n_local * (tree.n_nodes - 1))
+
+    ss = ShardedSampler(comm, device=local_rank)
+    ss.setup(model, tree, fp_own, n_global, capacity=16)
+    ss.dev.set_timing(False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        ss.reset()
+        return ss.run_mcmc(BURN_IN, BATCH, SEED, sweep_base=i * (BURN_IN + BATCH))
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ss.dev.kernel_time_ms()          # clear the timing accumulators
+    ss.dev.set_timing(True)          # HIP events around every colour-phase launch
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    el = time.perf_counter() - t0
+    ss.dev.set_timing(False)
+    avg_ms, n_launch = ss.dev.kernel_time_ms()
+
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    B = tree.n_nodes - 1
+    owned_total = n_global - 2
+    resamples = float(args.steps) * (BURN_IN + BATCH) * owned_total * B
+    value = resamples / el
+
+    if rank == 0:
+        bytes_per = algorithmic_bytes_per_resample(kbar, B)
+        per_launch_units = ss.owned_sites() / 3.0 * B
+        achieved = per_launch_units * bytes_per / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(args.config, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "site-branch path resamples/sec at n=1e6, 4-leaf tree",
+            "value": value, "unit": "site-branch resamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "tree.nwk (4 branches), n=%d sites per GPU, one step = "
+                                   "reset + run_mcmc(-L %d -B %d) as epievo_est_params_histories "
+                                   "drives it" % (n_local, BURN_IN, BATCH) if args.config == "tree"
+                       else "%s, n=%d per GPU" % (args.config, n_local),
+                       "sites_per_gpu": n_local, "branches": B, "burn_in": BURN_IN, "batch": BATCH,
+                       "mean_jumps_per_path": kbar, "sharding": "sites, 2-site halos, %d shard(s)" % world},
+            "roofline": {"bound": "hbm", "kernel": "epv_mh_phase_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "bytes_per_resample": bytes_per,
+                         "resamples_per_launch": per_launch_units, "avg_launch_ms": avg_ms,
+                         "launches_timed": n_launch},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, tree, fp_own)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
