@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc counter_collection CSVs (FETCH_SIZE and WRITE_SIZE collected
+in SEPARATE passes, as MI355X_MICROARCH.md prescribes) into per-kernel HBM bytes per
+launch, and write profiles/traffic.json for bench.py's roofline.traffic field.
+
+  python profiles/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <config> <round-tag>
+
+Units: FETCH_SIZE / WRITE_SIZE are KiB.  On gfx950 FETCH_SIZE reads half the bytes of a
+WIDE (16 B/lane) coalesced stream; this sampler's loads are 1-byte and 8-byte per lane,
+an uncalibrated width, so the raw value is reported and the x2-corrected read side is
+kept alongside as an upper bound.  WRITE_SIZE was checked on epv_reset_kernel, which
+writes exactly n*8 bytes of tri: 7812.5 KiB for n = 1e6, i.e. exact.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return {k: (len(v), sum(v) / len(v) * 1024.0) for k, v in acc.items()}
+
+
+def main():
+    fetch_csv, write_csv, config, tag = sys.argv[1:5]
+    f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    here = os.path.dirname(os.path.abspath(__file__))
+    rows = []
+    for k in sorted(set(f) | set(w)):
+        nf, bf = f.get(k, (0, 0.0))
+        nw, bw = w.get(k, (0, 0.0))
+        rows.append((k, nf, bf, bw))
+    with open(os.path.join(here, "%s_pmc_hbm_%s.csv" % (tag, config)), "w") as out:
+        out.write("kernel,launches,fetch_bytes_per_launch,write_bytes_per_launch,hbm_bytes_per_launch\n")
+        for k, n, bf, bw in rows:
+            out.write("%s,%d,%.0f,%.0f,%.0f\n" % (k, n, bf, bw, bf + bw))
+    tj = os.path.join(here, "traffic.json")
+    data = json.load(open(tj)) if os.path.exists(tj) else {}
+    mh = [r for r in rows if r[0] == "epv_mh_phase_kernel"][0]
+    data[config] = {"kernel": "epv_mh_phase_kernel", "round": tag,
+                    "fetch_bytes_per_launch": mh[2], "write_bytes_per_launch": mh[3],
+                    "hbm_bytes_per_launch": mh[2] + mh[3],
+                    "hbm_bytes_per_launch_fetch_x2": 2 * mh[2] + mh[3]}
+    json.dump(data, open(tj, "w"), indent=1, sort_keys=True)
+    print(json.dumps(data[config]))
+
+
+if __name__ == "__main__":
+    main()
