@@ -27,7 +27,10 @@ struct epv_ctx {
   std::vector<uint32_t> parent, subtree;
   std::vector<double> blen;
   EpvModelConst model{};
-  uint64_t first = 0, last = 0;
+  uint64_t first = 0, last = 0;          // fixed update range (no halo mode)
+  uint64_t halo_left = 0, halo_right = 0;  // halo mode: widths of the halo column blocks
+  bool halo_mode = false;
+  uint64_t phases_used = 0;              // colour phases run since the halos were fresh
   // device allocations
   EpvModelConst *d_model = nullptr;
   uint32_t *d_parent = nullptr, *d_subtree = nullptr;
@@ -107,14 +110,37 @@ int ensure_partials(epv_ctx *c) {
   return EPV_OK;
 }
 
+// Range of local sites a colour phase may update, and the owned range that statistics
+// and the accept counter cover.  In halo mode every phase since the last refresh makes
+// two more columns at each shard-internal edge stale (their own neighbours were not
+// available), so the updatable range shrinks by 2 per phase; the halo must be wide
+// enough that it never reaches the owned columns.
+void owned_range(const epv_ctx *c, uint64_t *lo, uint64_t *hi) {
+  if (!c->halo_mode) { *lo = c->first; *hi = c->last; return; }
+  *lo = c->halo_left ? c->halo_left : 1u;
+  *hi = c->halo_right ? c->S.n - c->halo_right - 1u : c->S.n - 2u;
+}
+int phase_range(epv_ctx *c, uint64_t *lo, uint64_t *hi) {
+  if (!c->halo_mode) { *lo = c->first; *hi = c->last; return EPV_OK; }
+  const uint64_t shrink = 2u * (c->phases_used + 1u);
+  *lo = c->halo_left ? shrink : 1u;
+  *hi = c->halo_right ? c->S.n - 1u - shrink : c->S.n - 2u;
+  if ((c->halo_left && *lo > c->halo_left) || (c->halo_right && *hi + c->halo_right < c->S.n - 1u))
+    return fail(c, EPV_ERR_STATE, "halo exhausted: refresh the halo columns (epv_put_columns + "
+                                  "epv_set_halo) before running more sweeps");
+  return EPV_OK;
+}
+
 // J/D of the current paths into d_partial[x][0..V); returns the buffer index via *which
 int launch_suffstats(epv_ctx *c, int *which) {
   int rc = ensure_partials(c);
   if (rc) return rc;
   const uint64_t nb = (c->S.n + 255u) / 256u;
   const uint32_t V = c->S.B * 16u;
+  uint64_t own_lo = 0, own_hi = 0;
+  owned_range(c, &own_lo, &own_hi);
   hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)nb), dim3(256), const_lds_bytes(c->S.N),
-                     c->stream, c->S, c->first, c->last, c->d_partial[0]);
+                     c->stream, c->S, own_lo, own_hi, c->d_partial[0]);
   uint64_t m = nb;
   int cur = 0;
   while (m > 1) {
@@ -130,7 +156,11 @@ int launch_suffstats(epv_ctx *c, int *which) {
 }
 
 int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
-  const uint64_t span = c->last - c->first + 1u;
+  uint64_t first = 0, last = 0, own_lo = 0, own_hi = 0;
+  int prc = phase_range(c, &first, &last);
+  if (prc) return prc;
+  owned_range(c, &own_lo, &own_hi);
+  const uint64_t span = last - first + 1u;
   const uint64_t threads = (span + 2u) / 3u;
   const uint64_t blocks = (threads + c->mh_threads - 1u) / c->mh_threads;
   if (blocks == 0) return EPV_OK;
@@ -149,9 +179,10 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   }
   hipLaunchKernelGGL(epv_mh_phase_kernel, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds,
                      c->stream, c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32),
-                     sweep, c->first, c->last, c->pool_entries, c->d_counters);
+                     sweep, first, last, own_lo, own_hi, c->pool_entries, c->d_counters);
   if (c->timing) HIP_TRY(c, hipEventRecord(e1, c->stream));
   HIP_TRY(c, hipGetLastError());
+  if (c->halo_mode) ++c->phases_used;
   return EPV_OK;
 }
 
@@ -316,6 +347,9 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   (void)hipFree(d_init); (void)hipFree(d_off); (void)hipFree(d_j);
   c->first = 1;
   c->last = n_sites - 2;
+  c->halo_mode = false;
+  c->halo_left = c->halo_right = 0;
+  c->phases_used = 0;
   c->have_paths = true;
   c->have_reset = false;
   return plan_mh(c);
@@ -336,6 +370,32 @@ EPV_API int epv_set_update_range(epv_ctx *c, uint64_t first, uint64_t last) {
     return fail(c, EPV_ERR_ARG, "shard needs a 2-site right halo");
   c->first = first;
   c->last = last;
+  c->halo_mode = false;
+  return EPV_OK;
+}
+
+EPV_API int epv_set_halo(epv_ctx *c, uint64_t left, uint64_t right) {
+  if (!c || !c->have_paths) return EPV_ERR_ARG;
+  if ((left && left < 2) || (right && right < 2) || left + right + 1 > c->S.n)
+    return fail(c, EPV_ERR_ARG, "halo blocks must be 0 or >= 2 columns and leave owned columns");
+  if (!left && c->S.g0 != 0) return fail(c, EPV_ERR_ARG, "a shard that does not start the genome needs a left halo");
+  if (!right && c->S.g0 + c->S.n != c->S.n_global)
+    return fail(c, EPV_ERR_ARG, "a shard that does not end the genome needs a right halo");
+  c->halo_left = left;
+  c->halo_right = right;
+  c->halo_mode = true;
+  c->phases_used = 0;
+  return EPV_OK;
+}
+
+EPV_API int epv_halo_phases_left(epv_ctx *c, uint64_t *phases) {
+  if (!c || !phases || !c->have_paths) return EPV_ERR_ARG;
+  if (!c->halo_mode || (!c->halo_left && !c->halo_right)) { *phases = ~0ull; return EPV_OK; }
+  uint64_t h = ~0ull;
+  if (c->halo_left) h = std::min(h, c->halo_left);
+  if (c->halo_right) h = std::min(h, c->halo_right);
+  const uint64_t total = h / 2u;  // phase p needs 2(p+1) <= halo
+  *phases = total > c->phases_used ? total - c->phases_used : 0;
   return EPV_OK;
 }
 

@@ -212,7 +212,8 @@ __device__ __forceinline__ double gtp(double r0, double r1, double h, double den
 
 __global__ __launch_bounds__(EPV_MH_THREADS) void epv_mh_phase_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
-    uint64_t first, uint64_t last, uint32_t pool_entries, unsigned long long *counters) {
+    uint64_t first, uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t pool_entries,
+    unsigned long long *counters) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   double *s_const = s_mem;                     // 20 + N doubles (padded to even)
   const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
@@ -484,7 +485,8 @@ __global__ __launch_bounds__(EPV_MH_THREADS) void epv_mh_phase_kernel(
         S.tri[site - 1] = llh_l;
         S.tri[site] = llh_m;
         S.tri[site + 1] = llh_r;
-        accepted = true;
+        // redundant updates of halo columns (site-sharded runs) are not counted
+        accepted = site >= own_first && site <= own_last;
       }
       pending = false;
     }

@@ -35,7 +35,8 @@ class _Counters(C.Structure):
 
 ABI_SYMBOLS = [
     "epv_create", "epv_destroy", "epv_last_error", "epv_set_tree", "epv_set_model",
-    "epv_upload_paths", "epv_set_global_length", "epv_set_update_range", "epv_reset", "epv_sweep",
+    "epv_upload_paths", "epv_set_global_length", "epv_set_update_range", "epv_set_halo",
+    "epv_halo_phases_left", "epv_reset", "epv_sweep",
     "epv_sweep_phase", "epv_run_mcmc", "epv_get_sufficient_statistics", "epv_scale_jump_times",
     "epv_paths_total_jumps", "epv_download_paths", "epv_get_tri_llh", "epv_column_bytes",
     "epv_get_columns", "epv_put_columns", "epv_get_counters", "epv_kernel_time_ms",
@@ -65,6 +66,8 @@ def lib():
         L.epv_upload_paths.argtypes = [vp, C.c_uint64, u8p, u64p, dp, C.c_uint32, C.c_uint64]
         L.epv_set_global_length.argtypes = [vp, C.c_uint64]
         L.epv_set_update_range.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.epv_set_halo.argtypes = [vp, C.c_uint64, C.c_uint64]
+        L.epv_halo_phases_left.argtypes = [vp, u64p]
         L.epv_reset.argtypes = [vp]
         L.epv_sweep.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, u64p]
         L.epv_sweep_phase.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint32, u64p]
@@ -133,6 +136,14 @@ class DeviceSampler:
 
     def set_update_range(self, first, last):
         self._ck(self.L.epv_set_update_range(self.h, first, last))
+
+    def set_halo(self, left, right):
+        self._ck(self.L.epv_set_halo(self.h, left, right))
+
+    def halo_phases_left(self):
+        v = C.c_uint64(0)
+        self._ck(self.L.epv_halo_phases_left(self.h, C.byref(v)))
+        return int(v.value)
 
     def reset(self):
         self._ck(self.L.epv_reset(self.h))

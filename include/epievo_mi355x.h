@@ -88,6 +88,19 @@ int epv_set_global_length(epv_ctx *ctx, uint64_t n_global);
  * Sites outside are read-only halo/boundary columns. */
 int epv_set_update_range(epv_ctx *ctx, uint64_t first, uint64_t last);
 
+/* Site-sharded runs with wide halos ("temporal blocking"): declare the first `left` and
+ * the last `right` local columns to be copies of the neighbouring shards' edge columns
+ * (0 = this side is the genome end).  Because the RNG and the colouring are keyed by
+ * the GLOBAL site index, a shard can update its halo columns redundantly and obtain
+ * exactly what the owner computes; every colour phase makes two more columns at each
+ * internal edge stale, so a halo of H columns lasts H/2 phases (H/6 sweeps) before
+ * the columns must be refreshed (epv_put_columns, then epv_set_halo again).  While
+ * this mode is on, sweeps shrink their update range automatically, and J/D and the
+ * accept count cover the owned columns only.  Calling it also marks the halos fresh. */
+int epv_set_halo(epv_ctx *ctx, uint64_t left, uint64_t right);
+/* how many more colour phases the current halos allow (UINT64_MAX when unbounded) */
+int epv_halo_phases_left(epv_ctx *ctx, uint64_t *phases);
+
 /* SingleSiteSampler::reset (SingleSiteSampler.cpp:449-475): cache the complete-data
  * log-likelihood of every interior triple. */
 int epv_reset(epv_ctx *ctx);

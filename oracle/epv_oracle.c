@@ -74,6 +74,7 @@ typedef struct {
 
 typedef struct orc_state {
   size_t n_sites;
+  size_t g0, n_global; /* site-sharded runs: global index of local site 0, genome length */
   int n_nodes;
   uint32_t *parent, *subtree;
   double *blen;
@@ -403,14 +404,13 @@ static double site_triple_llh(const orc_state *st, size_t c, const orc_path *pro
 /* ------------------------------------------------------------ MH update */
 /* SingleSiteSampler.cpp:482-536 (+ log_accept_rate :396-433) */
 static int mh_site(orc_state *st, size_t site, uint32_t sweep, orc_scratch *sc) {
-  const size_t n = st->n_sites;
   for (int node = 1; node < st->n_nodes; ++node)
     collect_segments(PATH(st, node, site - 1), PATH(st, node, site + 1), st->blen[node],
                      &sc->segs[node]);
   pruning(st, site, sc);
 
   orc_rng g;
-  g.st = st; g.site = (uint32_t)site; g.sweep = sweep;
+  g.st = st; g.site = (uint32_t)(st->g0 + site); g.sweep = sweep;
   double proposal_log_prob = 0.0;
   const int overflow = downward_sampling(st, site, sc, &g, &proposal_log_prob);
 
@@ -422,9 +422,9 @@ static int mh_site(orc_state *st, size_t site, uint32_t sweep, orc_scratch *sc) 
   double llr = orig_proposal - proposal_log_prob;
   const double llh_l_orig = llh_l, llh_r_orig = llh_r;
   if (!overflow) {
-    if (site > 1) llh_l = site_triple_llh(st, site - 1, sc->prop, 1);
+    if (st->g0 + site > 1) llh_l = site_triple_llh(st, site - 1, sc->prop, 1);
     llh_m = site_triple_llh(st, site, sc->prop, 0);
-    if (site < n - 2) llh_r = site_triple_llh(st, site + 1, sc->prop, -1);
+    if (st->g0 + site < st->n_global - 2) llh_r = site_triple_llh(st, site + 1, sc->prop, -1);
   }
   llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
 
@@ -474,6 +474,8 @@ ORC_API orc_state *orc_create(uint64_t n_sites, int n_nodes, const uint32_t *par
   if (n_nodes < 2 || n_nodes > ORC_MAX_NODES || n_sites < 3) return NULL;
   orc_state *st = (orc_state *)calloc(1, sizeof(orc_state));
   st->n_sites = n_sites;
+  st->g0 = 0;
+  st->n_global = n_sites;
   st->n_nodes = n_nodes;
   st->parent = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n_nodes);
   st->subtree = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n_nodes);
@@ -546,11 +548,38 @@ ORC_API uint64_t orc_sweep(orc_state *st, uint32_t sweep) {
     for (size_t s = 1; s + 1 < n; ++s) n_acc += (uint64_t)mh_site(st, s, sweep, &st->scr);
   } else {
     for (size_t c = 0; c < 3; ++c)
-      for (size_t s = (c == 0 ? 3 : c); s + 1 < n; s += 3)
-        n_acc += (uint64_t)mh_site(st, s, sweep, &st->scr);
+      for (size_t s = 1; s + 1 < n; ++s)
+        if ((st->g0 + s) % 3 == c) n_acc += (uint64_t)mh_site(st, s, sweep, &st->scr);
   }
   return n_acc;
 }
+
+/* ---- site-sharded runs (the multi-GPU driver's logic is tested against these) */
+ORC_API void orc_set_shard(orc_state *st, uint64_t g0, uint64_t n_global) {
+  st->g0 = g0; st->n_global = n_global;
+}
+/* one colour phase over local sites [first,last]; counts accepts inside [own_first,own_last] */
+ORC_API uint64_t orc_sweep_phase(orc_state *st, uint32_t colour, uint32_t sweep, uint64_t first,
+                                 uint64_t last, uint64_t own_first, uint64_t own_last) {
+  uint64_t n_acc = 0;
+  for (size_t s = first; s <= last; ++s)
+    if ((st->g0 + s) % 3 == colour) {
+      const int a = mh_site(st, s, sweep, &st->scr);
+      if (a && s >= own_first && s <= own_last) ++n_acc;
+    }
+  return n_acc;
+}
+/* overwrite the current path column of one site (halo refresh) */
+ORC_API void orc_set_site(orc_state *st, uint64_t site, const uint8_t *init, const uint32_t *cnt,
+                          const double *jumps) {
+  for (int b = 1; b < st->n_nodes; ++b) {
+    orc_path *p = PATH(st, b, site);
+    p->init = init[b - 1];
+    p->n = 0;
+    for (uint32_t j = 0; j < cnt[b - 1]; ++j) path_push(p, *jumps++);
+  }
+}
+ORC_API void orc_set_tri(orc_state *st, uint64_t site, double v) { st->tri_llh[site] = v; }
 
 /* one MH update of a single site (epievo_sim_pairwise.cpp:267-273 calls
  * Metropolis_Hastings_site per site itself) */
@@ -562,11 +591,13 @@ ORC_API int orc_mh_site(orc_state *st, uint64_t site, uint32_t sweep) {
 static void site_contrib(const orc_state *st, int b, size_t s, double J[8], double D[8]) {
   add_suff_stats(PATH(st, b, s - 1), PATH(st, b, s), PATH(st, b, s + 1), st->blen[b], J, D);
 }
+static size_t g_first = 0, g_last = (size_t)-1; /* owned range for the statistics */
 static void tree_sum(const orc_state *st, int b, size_t lo, size_t size, double out[16]) {
   for (int i = 0; i < 16; ++i) out[i] = 0.0;
   if (lo >= st->n_sites) return;
   if (size == 1) {
-    if (lo >= 1 && lo + 1 < st->n_sites) site_contrib(st, b, lo, out, out + 8);
+    if (lo >= 1 && lo + 1 < st->n_sites && lo >= g_first && lo <= g_last)
+      site_contrib(st, b, lo, out, out + 8);
     return;
   }
   double L[16], R[16];
@@ -579,7 +610,8 @@ ORC_API void orc_suffstats(const orc_state *st, double *J, double *D) {
   for (int i = 0; i < B * 8; ++i) { J[i] = 0.0; D[i] = 0.0; }
   if (st->reduce_mode == ORC_REDUCE_SEQ) {
     for (size_t s = 1; s + 1 < st->n_sites; ++s)
-      for (int b = 1; b <= B; ++b) site_contrib(st, b, s, J + (b - 1) * 8, D + (b - 1) * 8);
+      if (s >= g_first && s <= g_last)
+        for (int b = 1; b <= B; ++b) site_contrib(st, b, s, J + (b - 1) * 8, D + (b - 1) * 8);
   } else {
     size_t pad = 1;
     while (pad < st->n_sites) pad *= 2;
@@ -590,6 +622,13 @@ ORC_API void orc_suffstats(const orc_state *st, double *J, double *D) {
       memcpy(D + (b - 1) * 8, out + 8, 8 * sizeof(double));
     }
   }
+}
+
+ORC_API void orc_suffstats_range(const orc_state *st, uint64_t first, uint64_t last, double *J,
+                                 double *D) {
+  g_first = first; g_last = last;
+  orc_suffstats(st, J, D);
+  g_first = 0; g_last = (size_t)-1;
 }
 
 /* SingleSiteSampler.cpp:550-598.  J/D are batch averages on return. */

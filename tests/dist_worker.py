@@ -1,0 +1,46 @@
+"""Worker for the world_size>1 tests: runs ShardedSampler on a slice of a genome and
+writes its owned paths + J/D so the parent test can compare with the unsharded run.
+  python dist_worker.py <backend: oracle|hip> <cfg> <n_own> <burn> <batch> <em_iters> <outdir>
+Rendezvous via env (RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT); comm backend is gloo."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    backend, cfg, n_own, burn, batch, iters, outdir = sys.argv[1:8]
+    n_own, burn, batch, iters = int(n_own), int(burn), int(batch), int(iters)
+    import torch.distributed as dist
+    from common import simulate
+    from epievo_amd.parallel import ShardedSampler, TorchComm
+    dist.init_process_group("gloo")
+    comm = TorchComm(dist)
+    model, tree, fp = simulate(cfg, n_own * comm.world, seed=17)
+    own = fp.slice_sites(comm.rank * n_own, (comm.rank + 1) * n_own)
+    if backend == "oracle":
+        from fake_device import OracleDevice
+        ss = ShardedSampler(comm, device_factory=OracleDevice)
+    else:
+        ss = ShardedSampler(comm, device=0)
+    ss.setup(model, tree, own, fp.n_sites, capacity=16, sweeps_per_refresh=burn + batch)
+    out = {}
+    for it in range(iters):
+        ss.reset()
+        J, D, acc = ss.run_mcmc(burn, batch, 1234, sweep_base=it * (burn + batch))
+        out["J%d" % it], out["D%d" % it], out["acc%d" % it] = J, D, acc
+        ss.scale_jump_times(tree.branches * (1.0 + 0.01 * (it + 1)))
+        tree.branches[:] = tree.branches * (1.0 + 0.01 * (it + 1))
+    p = ss.owned_paths()
+    np.savez(os.path.join(outdir, "rank%d.npz" % comm.rank), init=p.init, offsets=p.offsets,
+             jumps=p.jumps, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

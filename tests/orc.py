@@ -51,6 +51,12 @@ def orc_lib():
         L.orc_sweep.restype = C.c_uint64
         L.orc_mh_site.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
         L.orc_suffstats.argtypes = [C.c_void_p, dp, dp]
+        L.orc_suffstats_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, dp, dp]
+        L.orc_set_shard.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.orc_sweep_phase.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_uint64] * 4
+        L.orc_sweep_phase.restype = C.c_uint64
+        L.orc_set_site.argtypes = [C.c_void_p, C.c_uint64, u8p, u32p, dp]
+        L.orc_set_tri.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
         L.orc_run_mcmc.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, dp, dp, u64p, dp]
         L.orc_scale_jump_times.argtypes = [C.c_void_p, dp]
         L.orc_total_jumps.argtypes = [C.c_void_p]
