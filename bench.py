@@ -93,7 +93,7 @@ def main():
     from epievo_amd import host
     from epievo_amd.parallel import ShardedSampler, TorchComm, NullComm
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from common import test_model, config
+    from common import ref_test_model, config
 
     dist = None
     if world > 1:
@@ -104,7 +104,7 @@ def main():
     else:
         comm = NullComm()
 
-    model = test_model()
+    model = ref_test_model()
     tree = config(args.config)
     n_local = args.sites
     n_global = n_local * world

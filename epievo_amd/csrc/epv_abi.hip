@@ -465,8 +465,9 @@ EPV_API int epv_sweep(epv_ctx *c, uint64_t n_sweeps, uint64_t seed, uint32_t swe
   return finish_mcmc(c, n_accepted, base);
 }
 
-EPV_API int epv_run_mcmc(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint64_t seed,
-                         uint32_t sweep_base, double *J, double *D, uint64_t *n_accepted) {
+EPV_API int epv_run_mcmc_sums(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint64_t seed,
+                              uint32_t sweep_base, int average, double *J, double *D,
+                              uint64_t *n_accepted) {
   int rc = check_ready(c, true);
   if (rc) return rc;
   if (!J || !D || batch == 0) return fail(c, EPV_ERR_ARG, "bad run_mcmc arguments");
@@ -494,13 +495,18 @@ EPV_API int epv_run_mcmc(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint64_t 
   std::vector<double> jd(V);
   HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_jd_acc, V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   rc = finish_mcmc(c, n_accepted, base);  // synchronises the stream
-  const double nb = (double)batch;
+  const double nb = average ? (double)batch : 1.0;
   for (uint32_t b = 0; b < c->S.B; ++b)
     for (int k = 0; k < 8; ++k) {
       J[b * 8 + k] = jd[b * 16 + k] / nb;       // batch average, SingleSiteSampler.cpp:589-594
       D[b * 8 + k] = jd[b * 16 + 8 + k] / nb;
     }
   return rc;
+}
+
+EPV_API int epv_run_mcmc(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint64_t seed,
+                         uint32_t sweep_base, double *J, double *D, uint64_t *n_accepted) {
+  return epv_run_mcmc_sums(c, burn_in, batch, seed, sweep_base, 1, J, D, n_accepted);
 }
 
 EPV_API int epv_get_sufficient_statistics(epv_ctx *c, double *J, double *D) {

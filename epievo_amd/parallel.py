@@ -181,14 +181,19 @@ class ShardedSampler:
         if self.comm.world > 1 and self.dev.halo_phases_left() < 3 * (burn_in + batch):
             raise RuntimeError("halo too narrow for %d sweeps: call reset() first or set up with "
                                "a larger sweeps_per_refresh" % (burn_in + batch))
-        J, D, nacc = self.dev.run_mcmc(burn_in, batch, seed, sweep_base)
-        if self.comm.world > 1:
-            # the one exchange per EM iteration: [J | D | n_acc] summed in rank order
+        if self.comm.world == 1:
+            J, D, nacc = self.dev.run_mcmc(burn_in, batch, seed, sweep_base)
+        else:
+            # shards return batch SUMS; the one exchange per EM iteration adds them in rank
+            # order ([J | D | n_acc]; J and n_acc are integers, hence exact) and the division
+            # by the batch size happens once, as in the unsharded run
+            J, D, nacc = self.dev.run_mcmc(burn_in, batch, seed, sweep_base, average=False)
             parts = self.comm.allgather(np.concatenate([J, D, [float(nacc)]]))
             tot = np.zeros_like(parts[0])
             for p in parts:
                 tot = tot + p
-            J, D, nacc = tot[:self.B * 8], tot[self.B * 8:self.B * 16], tot[-1]
+            J, D, nacc = (tot[:self.B * 8] / float(batch), tot[self.B * 8:self.B * 16] / float(batch),
+                          tot[-1])
         return J, D, nacc / float(batch * (self.n_global - 2))
 
     def scale_jump_times(self, new_branches):

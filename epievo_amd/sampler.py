@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "epv_create", "epv_destroy", "epv_last_error", "epv_set_tree", "epv_set_model",
     "epv_upload_paths", "epv_set_global_length", "epv_set_update_range", "epv_set_halo",
     "epv_halo_phases_left", "epv_reset", "epv_sweep",
-    "epv_sweep_phase", "epv_run_mcmc", "epv_get_sufficient_statistics", "epv_scale_jump_times",
+    "epv_sweep_phase", "epv_run_mcmc", "epv_run_mcmc_sums", "epv_get_sufficient_statistics", "epv_scale_jump_times",
     "epv_paths_total_jumps", "epv_download_paths", "epv_get_tri_llh", "epv_column_bytes",
     "epv_get_columns", "epv_put_columns", "epv_get_counters", "epv_kernel_time_ms",
     "epv_set_timing",
@@ -72,6 +72,7 @@ def lib():
         L.epv_sweep.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, u64p]
         L.epv_sweep_phase.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint32, u64p]
         L.epv_run_mcmc.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, dp, dp, u64p]
+        L.epv_run_mcmc_sums.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, dp, dp, u64p]
         L.epv_get_sufficient_statistics.argtypes = [vp, dp, dp]
         L.epv_scale_jump_times.argtypes = [vp, dp]
         L.epv_paths_total_jumps.argtypes = [vp, u64p]
@@ -158,11 +159,11 @@ class DeviceSampler:
         self._ck(self.L.epv_sweep_phase(self.h, colour, seed, sweep, C.byref(nacc)))
         return int(nacc.value)
 
-    def run_mcmc(self, burn_in, batch, seed, sweep_base=0):
+    def run_mcmc(self, burn_in, batch, seed, sweep_base=0, average=True):
         J, D = np.zeros(self.B * 8), np.zeros(self.B * 8)
         nacc = C.c_uint64(0)
-        self._ck(self.L.epv_run_mcmc(self.h, burn_in, batch, seed, sweep_base, _p(J, C.c_double),
-                                     _p(D, C.c_double), C.byref(nacc)))
+        self._ck(self.L.epv_run_mcmc_sums(self.h, burn_in, batch, seed, sweep_base, int(average),
+                                          _p(J, C.c_double), _p(D, C.c_double), C.byref(nacc)))
         return J, D, int(nacc.value)
 
     def suffstats(self):

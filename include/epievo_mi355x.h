@@ -123,6 +123,13 @@ int epv_sweep_phase(epv_ctx *ctx, int colour, uint64_t seed, uint32_t sweep,
 int epv_run_mcmc(epv_ctx *ctx, uint64_t burn_in, uint64_t batch, uint64_t seed,
                  uint32_t sweep_base, double *J, double *D, uint64_t *n_accepted);
 
+/* Same, but with average = 0 J/D return the SUMS over the batch sweeps: a site-sharded
+ * driver adds the shards' sums (exact for J) and divides once, which reproduces the
+ * unsharded averages bit-for-bit. */
+int epv_run_mcmc_sums(epv_ctx *ctx, uint64_t burn_in, uint64_t batch, uint64_t seed,
+                      uint32_t sweep_base, int average, double *J, double *D,
+                      uint64_t *n_accepted);
+
 /* get_sufficient_statistics, per-branch overload (ParamEstimation.cpp:92-114), over
  * the update range's triples, reduced in the canonical binary-tree order. */
 int epv_get_sufficient_statistics(epv_ctx *ctx, double *J, double *D);

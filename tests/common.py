@@ -23,7 +23,7 @@ def _tmp(name, text):
     return p
 
 
-def test_model():
+def ref_test_model():
     return host.Model.read(_tmp("test.param", TEST_PARAM_TEXT), scale=True)
 
 
@@ -43,6 +43,6 @@ def config(name):
 
 
 def simulate(name, n, seed=42):
-    m = test_model()
+    m = ref_test_model()
     t = config(name)
     return m, t, host.simulate(m, t, n, seed)

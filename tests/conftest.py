@@ -13,10 +13,10 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def test_model():
+def ref_test_model():
     """test/test.param of the reference (stationary 0.844912 0.893359 / baseline -0.8 -1.8)
     scaled to unit rate; values are the reference's own (golden/model.json pins them)."""
-    from common import test_model as tm
+    from common import ref_test_model as tm
     return tm()
 
 

@@ -74,7 +74,7 @@ class OracleDevice:
         self.o.L.orc_suffstats_range(self.o.h, lo, hi, orc._p(J, C.c_double), orc._p(D, C.c_double))
         return J, D
 
-    def run_mcmc(self, burn_in, batch, seed, sweep_base=0):
+    def run_mcmc(self, burn_in, batch, seed, sweep_base=0, average=True):
         w = sweep_base
         for _ in range(burn_in):
             self._sweep(seed, w)
@@ -86,7 +86,9 @@ class OracleDevice:
             J1, D1 = self.suffstats()
             J += J1
             D += D1
-        return J / float(batch), D / float(batch), nacc
+        if average:
+            return J / float(batch), D / float(batch), nacc
+        return J, D, nacc
 
     def scale_jump_times(self, nb):
         self.o.scale_jump_times(nb)

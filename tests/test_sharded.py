@@ -76,7 +76,7 @@ def _check(ranks, ref_res, ref_paths, n_nodes, n_own):
 
 @pytest.mark.parametrize("world,cfg,n_own", [(2, "tree", 400), (3, "pair", 300)])
 def test_sharded_oracle_gloo(world, cfg, n_own):
-    burn, batch, iters = 1, 2, 2
+    burn, batch, iters = 1, 3, 2
     ranks = _run_ranks(world, "oracle", cfg, n_own, burn, batch, iters, 29611 + world)
     ref_res, ref_paths, tree = _unsharded(_OracleEngine, cfg, n_own * world, burn, batch, iters)
     _check(ranks, ref_res, ref_paths, tree.n_nodes, n_own)
