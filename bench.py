@@ -13,8 +13,10 @@ O(8) host M-step are outside it.
 
   python bench.py --gpus N --steps K --warmup W
 For N > 1 it is launched by torch.distributed.run (one rank per GPU, RCCL): the genome
-of N * n sites is cut into contiguous shards with 2-site halos; boundary columns are
-exchanged after every colour phase and J/D are all-reduced once per step.
+of N * n sites is cut into contiguous shards with wide halos that each rank updates
+redundantly (the RNG is keyed by the global site index), so one step needs exactly two
+exchanges: a halo refresh before reset() and one all-gather of J/D afterwards
+(epievo_amd/parallel.py).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -78,6 +80,9 @@ def main():
     ap.add_argument("--sites", type=int, default=N_SITES, help="sites per GPU")
     ap.add_argument("--config", default="tree", choices=["tree", "pair", "bal16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) is the product path; gloo lets several ranks share one "
+                         "GPU to rehearse the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,9 +103,15 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        comm = TorchComm(dist, torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            comm = TorchComm(dist, torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+            comm = TorchComm(dist)
     else:
         comm = NullComm()
 
@@ -140,7 +151,7 @@ def main():
     avg_ms, n_launch = ss.dev.kernel_time_ms()
 
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -171,7 +182,7 @@ def main():
                                    "drives it" % (n_local, BURN_IN, BATCH) if args.config == "tree"
                        else "%s, n=%d per GPU" % (args.config, n_local),
                        "sites_per_gpu": n_local, "branches": B, "burn_in": BURN_IN, "batch": BATCH,
-                       "mean_jumps_per_path": kbar, "sharding": "sites, 2-site halos, %d shard(s)" % world},
+                       "mean_jumps_per_path": kbar, "sharding": "contiguous site shards, %d-column redundant halos refreshed once per step, %d shard(s)" % (ss.halo, world)},
             "roofline": {"bound": "hbm", "kernel": "epv_mh_phase_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_resample": bytes_per,

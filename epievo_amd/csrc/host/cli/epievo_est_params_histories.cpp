@@ -1,0 +1,151 @@
+// epievo_est_params_histories -- MI355X drop-in for the reference's MCEM driver
+// (/root/reference/src/prog/epievo_est_params_histories.cpp:93-300): same flags, same
+// positionals, same param / Newick / local_paths formats, same per-iteration outputs and
+// -v TSV line.  The E-step (reset + run_mcmc) and scale_jump_times run on the GPU; the
+// O(8) M-step runs on the host.
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <random>
+#include <stdexcept>
+
+#include "epv_io.hpp"
+#include "epv_model.hpp"
+#include "epv_options.hpp"
+#include "epv_sampler.hpp"
+
+using std::cerr;
+using std::endl;
+using std::string;
+using std::vector;
+
+static string strip_path(const string &full) {
+  const size_t p = full.find_last_of('/');
+  return p == string::npos ? full : full.substr(p + 1);
+}
+
+int main(int argc, const char **argv) {
+  try {
+    bool VERBOSE = false, single_branch = false, optimize_branches = false;
+    string outfile, param_file_updated, tree_file, treefile_updated;
+    size_t iteration = 10, batch = 10, burnin = 10;
+    size_t rng_seed = std::numeric_limits<size_t>::max();
+    static const double param_tol = 1e-10;
+
+    epv::OptionParser opt_parse(strip_path(argv[0]), "estimate parameters and evolutionary histories",
+                                "<param> (<treefile>) <path_file>");
+    opt_parse.add_opt("iteration", 'i', "number of MCMC-EM iteration", false, iteration);
+    opt_parse.add_opt("batch", 'B', "number of MCMC iteration", false, batch);
+    opt_parse.add_opt("burnin", 'L', "MCMC burn-in length", false, burnin);
+    opt_parse.add_opt("seed", 's', "rng seed", false, rng_seed);
+    opt_parse.add_opt("outfile", 'o', "output file of local paths", true, outfile);
+    opt_parse.add_opt("outparam", 'p', "output file of parameters", false, param_file_updated);
+    opt_parse.add_opt("outtree", 't', "output file of tree", false, treefile_updated);
+    opt_parse.add_opt("single_branch", 'T', "pairwise process (assumes no tree)", false, single_branch);
+    opt_parse.add_opt("branch", 'b', "optimize branch lengths", false, optimize_branches);
+    opt_parse.add_opt("verbose", 'v', "print more run info", false, VERBOSE);
+    vector<string> leftover_args;
+    opt_parse.parse(argc, argv, leftover_args);
+    if (argc == 1 || opt_parse.help_requested()) {
+      cerr << opt_parse.help_message() << endl << opt_parse.about_message() << endl;
+      return EXIT_SUCCESS;
+    }
+    if (opt_parse.option_missing()) {
+      cerr << opt_parse.option_missing_message() << endl;
+      return EXIT_SUCCESS;
+    }
+    if (leftover_args.size() == 2) {
+      if (!single_branch) { cerr << opt_parse.help_message() << endl; return EXIT_SUCCESS; }
+    } else if (leftover_args.size() != 3) {
+      cerr << opt_parse.help_message() << endl;
+      return EXIT_SUCCESS;
+    } else {
+      tree_file = leftover_args[1];
+    }
+    const string param_file(leftover_args.front()), input_file(leftover_args.back());
+
+    if (VERBOSE) cerr << "[READING PARAMETERS: " << param_file << "]" << endl;
+    epv::Model the_model = epv::Model::read(param_file);
+    the_model.scale_triplet_rates();
+
+    if (VERBOSE) cerr << "[READING PATHS FILE: " << input_file << "]" << endl;
+    vector<string> node_names;
+    vector<double> tot_times;
+    epv::FlatPaths paths = epv::read_local_paths(input_file, node_names, tot_times);
+
+    epv::Tree th;
+    if (single_branch) {
+      if (VERBOSE) cerr << "[INITIALIZING TWO NODE TREE WITH TIME: " << tot_times.back() << "]" << endl;
+      th = epv::Tree::single_branch(tot_times.back());
+    } else {
+      if (VERBOSE) cerr << "[READING TREE: " << tree_file << "]" << endl;
+      th = epv::Tree::read(tree_file);
+    }
+    if (th.n_nodes() != paths.n_nodes)
+      throw std::runtime_error("tree and paths file have different numbers of nodes");
+    for (int b = 1; b < th.n_nodes(); ++b)
+      if (tot_times[b] != th.branches[b])
+        throw std::runtime_error("paths file tot_time differs from the tree's branch length at node " +
+                                 th.node_names[b]);
+
+    if (rng_seed == std::numeric_limits<size_t>::max()) {
+      std::random_device rd;
+      rng_seed = rd();
+    }
+    if (VERBOSE) {
+      cerr << "rng seed: " << rng_seed << endl;
+      cerr << "itr\tstationary\tbaseline\tinit\tacc_rate\tllh\t\n";
+      cerr << "0" << "\t" << the_model.T[0] << "\t" << the_model.T[3] << "\t" << the_model.baseline[0]
+           << "\t" << the_model.baseline[3] << endl;
+    }
+
+    epv::SingleSiteSampler mcmc(burnin, batch);
+    for (size_t itr = 0; itr < iteration; itr++) {
+      if (itr == 0) mcmc.reset(the_model, th, paths);
+      else mcmc.reset(the_model);
+
+      double acceptance_rate;
+      vector<vector<double>> J_accum, D_accum;
+      mcmc.run_mcmc(rng_seed, itr, J_accum, D_accum, acceptance_rate);
+
+      /* PARAMETER ESTIMATION (host) */
+      const int B = th.n_nodes() - 1;
+      vector<double> J(B * 8), D(B * 8);
+      for (int b = 1; b <= B; ++b)
+        for (int i = 0; i < 8; ++i) { J[(b - 1) * 8 + i] = J_accum[b][i]; D[(b - 1) * 8 + i] = D_accum[b][i]; }
+      double llh = 0.0;
+      if (!optimize_branches) {
+        llh = epv::estimate_rates(param_tol, th.n_nodes(), J.data(), D.data(), the_model);
+        epv::set_one_change_per_site_per_unit_time(the_model.rates, th.branches);
+      } else {
+        llh = epv::estimate_rates_and_branches(param_tol, th.n_nodes(), J.data(), D.data(), th.branches,
+                                               the_model);
+      }
+      mcmc.scale_jump_times(th.branches);
+
+      if (VERBOSE)
+        cerr << itr + 1 << "\t" << the_model.T[0] << "\t" << the_model.T[3] << "\t"
+             << the_model.baseline[0] << "\t" << the_model.baseline[3] << "\t" << acceptance_rate
+             << "\t" << llh << endl;
+
+      if (!param_file_updated.empty()) {
+        std::ofstream out_param(param_file_updated);
+        if (!out_param) throw std::runtime_error("bad output param file: " + param_file_updated);
+        out_param << the_model.format_for_param_file() << endl;
+      }
+      mcmc.download(paths);
+      epv::write_local_paths(outfile, th.node_names, th.n_nodes(), paths.n_sites, th.branches.data(),
+                             paths.init.data(), paths.offsets.data(), paths.jumps.data());
+      if (optimize_branches && !treefile_updated.empty()) {
+        std::ofstream out_tree(treefile_updated);
+        if (!out_tree) throw std::runtime_error("bad output param file: " + treefile_updated);
+        out_tree << th.newick() << endl;
+      }
+    }
+  } catch (const std::exception &e) {
+    cerr << e.what() << endl;
+    return EXIT_FAILURE;
+  }
+  return EXIT_SUCCESS;
+}

@@ -1,0 +1,81 @@
+// epv_sampler.cpp -- see epv_sampler.hpp
+#include "epv_sampler.hpp"
+
+#include <stdexcept>
+#include <string>
+
+#include "epievo_mi355x.h"
+
+namespace epv {
+
+SingleSiteSampler::SingleSiteSampler(size_t n_burn_in, size_t n_batch, int device, uint32_t capacity)
+    : SAMPLE_ROOT(false), burn_in(n_burn_in), batch(n_batch), ctx_(epv_create(device)),
+      capacity_(capacity) {
+  if (!ctx_)
+    throw std::runtime_error("cannot open HIP device " + std::to_string(device) +
+                             " (this build has no CPU fallback)");
+}
+
+SingleSiteSampler::~SingleSiteSampler() { epv_destroy(ctx_); }
+
+void SingleSiteSampler::check(int rc, const char *what) {
+  if (rc != EPV_OK) throw std::runtime_error(std::string(what) + ": " + epv_last_error(ctx_));
+}
+
+void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &paths) {
+  n_nodes_ = th.n_nodes();
+  n_sites_ = paths.n_sites;
+  check(epv_set_tree(ctx_, th.n_nodes(), th.parent_ids.data(), th.subtree_sizes.data(),
+                     th.branches.data()), "epv_set_tree");
+  check(epv_upload_paths(ctx_, paths.n_sites, paths.init.data(), paths.offsets.data(),
+                         paths.jumps.data(), capacity_, 0), "epv_upload_paths");
+  reset(m);
+}
+
+void SingleSiteSampler::reset(const Model &m) {
+  check(epv_set_model(ctx_, m.rates.data(), m.T.data()), "epv_set_model");
+  check(epv_reset(ctx_), "epv_reset");
+}
+
+void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
+                                 std::vector<std::vector<double>> &J,
+                                 std::vector<std::vector<double>> &D, double &acceptance_rate) {
+  const size_t B = (size_t)n_nodes_ - 1;
+  std::vector<double> Jf(B * 8), Df(B * 8);
+  uint64_t n_acc = 0;
+  const uint32_t base = (uint32_t)(em_iteration * (burn_in + batch));
+  check(epv_run_mcmc(ctx_, burn_in, batch, seed, base, Jf.data(), Df.data(), &n_acc), "epv_run_mcmc");
+  J.assign(n_nodes_, {});
+  D.assign(n_nodes_, {});
+  for (size_t b = 1; b <= B; ++b) {
+    J[b].assign(Jf.begin() + (b - 1) * 8, Jf.begin() + b * 8);
+    D[b].assign(Df.begin() + (b - 1) * 8, Df.begin() + b * 8);
+  }
+  acceptance_rate = static_cast<double>(n_acc) / (batch * (n_sites_ - 2));
+}
+
+size_t SingleSiteSampler::sweeps(size_t n, uint64_t seed, uint32_t sweep_base) {
+  uint64_t n_acc = 0;
+  check(epv_sweep(ctx_, n, seed, sweep_base, &n_acc), "epv_sweep");
+  return n_acc;
+}
+
+void SingleSiteSampler::scale_jump_times(const std::vector<double> &new_branches) {
+  check(epv_scale_jump_times(ctx_, new_branches.data()), "epv_scale_jump_times");
+}
+
+void SingleSiteSampler::download(FlatPaths &paths) {
+  uint64_t total = 0;
+  check(epv_paths_total_jumps(ctx_, &total), "epv_paths_total_jumps");
+  paths.n_sites = n_sites_;
+  paths.n_nodes = n_nodes_;
+  const uint64_t E = (uint64_t)(n_nodes_ - 1) * n_sites_;
+  paths.init.assign(E, 0);
+  paths.offsets.assign(E + 1, 0);
+  paths.jumps.assign(total ? total : 1, 0.0);
+  check(epv_download_paths(ctx_, paths.init.data(), paths.offsets.data(), paths.jumps.data()),
+        "epv_download_paths");
+  paths.jumps.resize(total);
+}
+
+}  // namespace epv

@@ -1,0 +1,68 @@
+// epv_sampler.hpp -- host-side C++ face of the GPU sampler, shaped like the reference's
+// SingleSiteSampler (/root/reference/src/libepievo/SingleSiteSampler.hpp:35-81) so that
+// the EM driver reads like the reference's (epievo_est_params_histories.cpp:236-264).
+// It is a thin wrapper over the C ABI of include/epievo_mi355x.h; errors become
+// std::runtime_error (the reference's mains catch std::exception and return
+// EXIT_FAILURE, epievo_est_params_histories.cpp:296-299).
+//
+// Differences forced by the device boundary:
+//  * paths live on the GPU between calls: reset(model, tree, paths) uploads them once,
+//    reset(model) re-derives the cached log-likelihoods after a model change, and
+//    download(paths) brings them back when the driver wants to write them;
+//  * the reference threads one std::mt19937 through every call; the parallel schedule
+//    uses a counter-based stream, so run_mcmc takes (seed, em_iteration) instead.
+#ifndef EPV_SAMPLER_HPP
+#define EPV_SAMPLER_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "epv_io.hpp"
+#include "epv_model.hpp"
+
+struct epv_ctx;
+
+namespace epv {
+
+class SingleSiteSampler {
+public:
+  SingleSiteSampler(size_t n_burn_in, size_t n_batch, int device = 0, uint32_t capacity = 0);
+  ~SingleSiteSampler();
+  SingleSiteSampler(const SingleSiteSampler &) = delete;
+  SingleSiteSampler &operator=(const SingleSiteSampler &) = delete;
+
+  // SingleSiteSampler::reset (SingleSiteSampler.cpp:449-475)
+  void reset(const Model &the_model, const Tree &th, const FlatPaths &paths);
+  void reset(const Model &the_model);
+
+  // SingleSiteSampler::run_mcmc (:550-598).  J/D are resized to n_nodes rows of 8 (row 0
+  // empty) and hold batch averages, exactly as the reference returns them.
+  void run_mcmc(uint64_t seed, uint64_t em_iteration, std::vector<std::vector<double>> &J_all_sites,
+                std::vector<std::vector<double>> &D_all_sites, double &acceptance_rate);
+
+  // `n` x single_iteration (:538-548); epievo_sim_pairwise.cpp:267-273 spells this loop
+  // out with Metropolis_Hastings_site.  Returns the number of accepted proposals.
+  size_t sweeps(size_t n, uint64_t seed, uint32_t sweep_base);
+
+  // scale_jump_times (ParamEstimation.cpp:369-380)
+  void scale_jump_times(const std::vector<double> &new_branches);
+
+  void download(FlatPaths &paths);
+
+  // MCMC parameter constants (public fields of the reference class)
+  bool SAMPLE_ROOT;  // hard-wired false in the reference (SingleSiteSampler.cpp:441)
+  size_t burn_in;
+  size_t batch;
+
+private:
+  void check(int rc, const char *what);
+  epv_ctx *ctx_;
+  uint32_t capacity_;
+  int n_nodes_ = 0;
+  uint64_t n_sites_ = 0;
+};
+
+}  // namespace epv
+
+#endif

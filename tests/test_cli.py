@@ -1,0 +1,81 @@
+"""The drop-in CLIs on the GPU: epievo_est_params_histories / epievo_sim_pairwise keep the
+reference's flags and file formats, and their outputs equal an EM loop driven through the
+CPU oracle's parallel rung (bit-identical param text and local_paths bytes)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from common import simulate, TEST_PARAM_TEXT, TREE_NWK_TEXT
+from epievo_amd import _build, host
+
+pytestmark = pytest.mark.gpu
+BIN = _build.BIN_DIR
+
+
+def _oracle_em(model, tree, fp, iters, burn, batch, seed, optimize):
+    o = orc.Oracle(tree, model, fp, "B", cap=max(16, 2 * int(fp.counts().max()) + 8), seed=seed)
+    branches = tree.branches.copy()
+    text = ""
+    for it in range(iters):
+        o.set_model(model)
+        o.reset()
+        J, D, nacc, acc = o.run_mcmc(burn, batch, sweep_base=it * (burn + batch))
+        model, branches, llh, text = host.m_step(model, branches, J, D, optimize_branches=optimize)
+        o.scale_jump_times(branches)
+    return model, branches, text, o.paths()
+
+
+@pytest.mark.parametrize("optimize", [False, True])
+def test_est_params_histories_matches_oracle_em(tmp_path, optimize):
+    model, tree, fp = simulate("tree", 3000, seed=21)
+    d = str(tmp_path)
+    open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+    host.write_paths(d + "/in.paths", tree.node_names, tree.branches, fp)
+    cmd = [os.path.join(BIN, "epievo_est_params_histories"), "-i", "2", "-B", "3", "-L", "2", "-s", "77",
+           "-o", d + "/out.paths", "-p", d + "/out.param", "-t", d + "/out.nwk", "-v"]
+    if optimize:
+        cmd.append("-b")
+    cmd += [d + "/p.param", d + "/t.nwk", d + "/in.paths"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stderr.split("\n") if l and l[0].isdigit()]
+    assert len(lines) == 3 and len(lines[2].split("\t")) == 7      # itr T00 T11 b00 b11 acc llh
+    m2, br, text, paths = _oracle_em(model, tree, fp, 2, 2, 3, 77, optimize)
+    assert open(d + "/out.param").read() == text + "\n"
+    host.write_paths(d + "/exp.paths", tree.node_names, br, paths)
+    assert open(d + "/out.paths", "rb").read() == open(d + "/exp.paths", "rb").read()
+    if optimize:
+        t2 = host.Tree.read(d + "/out.nwk")
+        np.testing.assert_allclose(t2.branches, br, rtol=1e-5)       # default stream precision
+
+
+def test_sim_pairwise_runs_and_keeps_end_states(tmp_path):
+    model, tree, fp = simulate("pair", 2000, seed=3)
+    d = str(tmp_path)
+    open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
+    root = fp.init
+    leaf = fp.init ^ (fp.counts() & 1).astype(np.uint8)
+    with open(d + "/obs.states", "w") as f:
+        f.write("#root\tleaf\n")
+        for i in range(fp.n_sites):
+            f.write("%d\t%d\t%d\n" % (i, root[i], leaf[i]))
+    r = subprocess.run([os.path.join(BIN, "epievo_sim_pairwise"), "-L", "5", "-T", "1.0", "-s", "9",
+                        "-o", d + "/out.paths", d + "/p.param", d + "/obs.states"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out, names, tt = host.read_paths(d + "/out.paths")
+    assert names == ["root", "leaf"] and tt[1] == 1.0
+    assert np.array_equal(out.init, root)
+    assert np.array_equal(out.init ^ (out.counts() & 1).astype(np.uint8), leaf)
+    # error behaviour: bad file -> message on stderr, EXIT_FAILURE (main's catch block)
+    r = subprocess.run([os.path.join(BIN, "epievo_sim_pairwise"), "-o", d + "/x", d + "/nope", d + "/obs.states"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not open file" in r.stderr
+    # missing required -o -> message, EXIT_SUCCESS (as the reference does)
+    r = subprocess.run([os.path.join(BIN, "epievo_sim_pairwise"), d + "/p.param", d + "/obs.states"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "required" in r.stderr
