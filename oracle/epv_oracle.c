@@ -718,6 +718,39 @@ ORC_API void orc_kat_suffstats(int l_init, uint32_t nl, const double *lj, int m_
            r = {(uint8_t)r_init, nr, nr, (double *)rj};
   add_suff_stats(&l, &m, &r, tot_time, J, D);
 }
+/* end-conditioned sampler alone: n samples of a 2-state path a->b on [0,T] by forward
+ * rejection (sample i uses Philox site index i); returns the means of
+ * (#jumps 0->1, #jumps 1->0, time spent in state 0) -- to be compared with the
+ * reference's closed forms expectation_J / expectation_D. */
+ORC_API void orc_kat_end_cond_means(int rng_mode, int math_mode, uint64_t seed, double r0,
+                                    double r1, int a, int b, double T, uint64_t n, double *out) {
+  orc_state st;
+  memset(&st, 0, sizeof(st));
+  st.rng_mode = rng_mode; st.math_mode = math_mode; st.seed = seed; st.cap = 0;
+  set_math(&st);
+  orc_mt_seed(&st.mt, (uint32_t)seed);
+  orc_scratch sc;
+  memset(&sc, 0, sizeof(sc));
+  orc_path p;
+  memset(&p, 0, sizeof(p));
+  double j01 = 0, j10 = 0, d0 = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    orc_rng g;
+    g.st = &st; g.site = (uint32_t)i; g.sweep = 0;
+    p.n = 0;
+    forward_rejection(&st, &sc, &g, 1, 0, r0, r1, a, b, T, 0.0, &p);
+    int s = a;
+    double prev = 0.0;
+    for (uint32_t k = 0; k < p.n; ++k) {
+      if (s == 0) { j01 += 1.0; d0 += p.t[k] - prev; } else j10 += 1.0;
+      prev = p.t[k]; s ^= 1;
+    }
+    if (s == 0) d0 += T - prev;
+  }
+  out[0] = j01 / (double)n; out[1] = j10 / (double)n; out[2] = d0 / (double)n;
+  free(p.t); free(sc.trial);
+}
+
 ORC_API double orc_kat_exp(double x) { return orc_exp(x); }
 ORC_API double orc_kat_log(double x) { return orc_log(x); }
 ORC_API void orc_kat_exp_log_array(const double *x, uint64_t n, double *e, double *l) {

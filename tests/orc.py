@@ -70,6 +70,7 @@ def orc_lib():
                                        C.c_double, dp, dp, u64p, u64p, dp]
         L.orc_kat_suffstats.argtypes = [C.c_int, C.c_uint32, dp, C.c_int, C.c_uint32, dp, C.c_int,
                                         C.c_uint32, dp, C.c_double, dp, dp]
+        L.orc_kat_end_cond_means.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_uint64, dp]
         L.orc_kat_exp.argtypes = [C.c_double]
         L.orc_kat_exp.restype = C.c_double
         L.orc_kat_log.argtypes = [C.c_double]
