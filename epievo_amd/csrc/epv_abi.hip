@@ -73,6 +73,7 @@ void dfree(T *&p) {
 
 void free_paths(epv_ctx *c) {
   dfree(c->S.meta); dfree(c->S.jumps); dfree(c->S.sel); dfree(c->S.tri);
+  dfree(c->S.prop_llr); dfree(c->S.prop_flag); dfree(c->S.prop_states); dfree(c->S.tasks);
   dfree(c->d_partial[0]); dfree(c->d_partial[1]);
   c->partial_cap = 0;
   c->have_paths = c->have_reset = false;
@@ -177,9 +178,20 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     ++c->ev_used;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
   }
-  hipLaunchKernelGGL(epv_mh_phase_kernel, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds,
+  hipLaunchKernelGGL(epv_mh_propose_kernel, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds,
                      c->stream, c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32),
-                     sweep, first, last, own_lo, own_hi, c->pool_entries, c->d_counters);
+                     sweep, first, last, c->pool_entries, c->d_counters);
+  {
+    // one lane per dirty (site, branch) pair; the count is only known on the device, so
+    // launch a grid that covers the typical case and grid-stride over the rest
+    const uint64_t max_tasks = threads * c->S.B;
+    const uint64_t jb = std::min<uint64_t>((max_tasks + 255u) / 256u, 2048u);
+    hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb), dim3(256), const_lds_bytes(c->S.N),
+                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, c->d_counters);
+  }
+  hipLaunchKernelGGL(epv_mh_accept_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256),
+                     const_lds_bytes(c->S.N), c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->d_counters);
   if (c->timing) HIP_TRY(c, hipEventRecord(e1, c->stream));
   HIP_TRY(c, hipGetLastError());
   if (c->halo_mode) ++c->phases_used;
@@ -229,7 +241,7 @@ EPV_API epv_ctx *epv_create(int device_id) {
     return nullptr;
   }
   // the MH kernel asks for more dynamic LDS than the 64 KiB default
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_phase_kernel),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return c;
 }
@@ -328,6 +340,11 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   HIP_TRY(c, hipMalloc(&c->S.jumps, 2u * E * capacity * sizeof(double)));
   HIP_TRY(c, hipMalloc(&c->S.sel, n_sites));
   HIP_TRY(c, hipMalloc(&c->S.tri, n_sites * sizeof(double)));
+  HIP_TRY(c, hipMalloc(&c->S.prop_llr, n_sites * sizeof(double)));
+  HIP_TRY(c, hipMalloc(&c->S.prop_flag, n_sites));
+  c->S.W = (2u * capacity + 1u + 63u) / 64u;
+  HIP_TRY(c, hipMalloc(&c->S.prop_states, E * c->S.W * sizeof(uint64_t)));
+  HIP_TRY(c, hipMalloc(&c->S.tasks, ((n_sites + 2u) / 3u + 1u) * B * sizeof(unsigned long long)));
   HIP_TRY(c, hipMemsetAsync(c->S.meta, 0, 2u * E, c->stream));
   // staging of the CSR form
   uint8_t *d_init = nullptr;

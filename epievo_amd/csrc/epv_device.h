@@ -6,6 +6,7 @@
 //   sel  [n]           u8   which of the two buffers holds the CURRENT path of a site
 //   tri  [n]           f64  cached complete-data log-likelihood of the triple centred
 //                           at each site (SingleSiteSampler's private tri_llh)
+//   prop_llr [n] f64, prop_flag [n] u8   hand-over from the propose to the accept kernel
 // Lanes of a wavefront map to sites, so meta/sel/tri/jump-plane loads are unit- or
 // stride-3-coalesced.  The proposal of a site is written straight into the site's
 // OTHER buffer; accepting it is a one-byte flip of sel[site] (no copy), rejecting it
@@ -35,6 +36,11 @@ struct EpvDev {
   double *jumps;
   uint8_t *sel;
   double *tri;
+  double *prop_llr;   // [n] q(old)-q(new) of the pending proposal (propose -> accept kernel)
+  uint8_t *prop_flag; // [n] 1 = the pending proposal overflowed the capacity
+  uint64_t *prop_states;  // [B][n][W] sampled segment end states of the pending proposal, 1 bit each
+  unsigned long long *tasks;  // dirty (branch<<40 | site) pairs of the current colour phase
+  uint32_t W;        // 64-bit words per (site, branch) in prop_states = ceil((2C+1)/64)
   const EpvModelConst *model;  // device copy
   const uint32_t *parent;      // [N]
   const uint32_t *subtree;     // [N]
@@ -42,6 +48,6 @@ struct EpvDev {
 };
 
 // counters[] slots
-enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_N = 4 };
+enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_N = 4 };
 
 #endif

@@ -7,7 +7,8 @@
 // sampler, not a contraction.
 //
 // What each kernel replaces in the reference (/root/reference/src/libepievo):
-//   epv_mh_phase_kernel    SingleSiteSampler::Metropolis_Hastings_site (SingleSiteSampler.cpp:482-536)
+//   epv_mh_propose_kernel + epv_mh_accept_kernel
+//                          SingleSiteSampler::Metropolis_Hastings_site (SingleSiteSampler.cpp:482-536)
 //                          = collect_segment_info (Segment.cpp:35-79) + pruning (:145-157)
 //                          + downward_sampling (:227-255) + end_cond_sample_forward_rejection
 //                          (EndCondSampling.cpp:479-509) + log_accept_rate (:396-433)
@@ -155,32 +156,51 @@ enum { TRIAL_FAIL = 0, TRIAL_OK = 1, TRIAL_OVERFLOW = 2 };
 
 // forward_sampling (EndCondSampling.cpp:466-476) for trial t of segment (node,k):
 // hold times ~ Exp(rate of the current state) = -log(1-u)/rate until T is passed.
-// `room` = jump slots left in this path; when STORE, jump times (+start_time) are
-// written to dst[0], dst[n], ...   Returns the outcome and the jump count.
-template <bool STORE>
+// `u0` is the trial's first draw (its Philox block is shared, see epv_philox.h); later
+// draws come from the trial's own blocks.  `room` = jump slots left in this path.
+// Jump times (+start_time) are written to dst[0], dst[stride], ... for the first
+// `max_store` jumps only (0 = store nothing); the count is always complete.
+//
+// Shortcut (execution only, results unchanged): ~95 % of trials on short branches end
+// at the first draw because no jump falls inside the segment, i.e. 1-u0 <= exp(-rate*T).
+// `nojump0/1` = that bound for start state 0/1 from a float exp, shrunk by 1e-4 -- far
+// more than the float error (~1e-5 for rate*T < 40) and astronomically more than the
+// fp64 rounding of the exact test -- so "1-u0 < nojump" PROVES the exact computation
+// -log(1-u0)/rate >= T without evaluating log or the division.  Everything else takes
+// the exact path below, so the outcome is always the one the oracle computes.
 __device__ __forceinline__ int run_trial(uint32_t seed_lo, uint32_t seed_hi, uint32_t gsite,
                                          uint32_t sweep, uint32_t node, uint32_t k, uint32_t t,
-                                         uint32_t a0, uint32_t end, double T, double r0,
-                                         double r1, uint32_t room, double *dst, uint64_t n,
+                                         double u0, uint32_t a0, uint32_t end, double T, double r0,
+                                         double r1, double nojump0, double nojump1, uint32_t room,
+                                         double *dst, uint64_t stride, uint32_t max_store,
                                          double start_time, uint32_t &nj_out) {
+  nj_out = 0;
+  if (1.0 - u0 < (a0 ? nojump1 : nojump0)) return (a0 == end) ? TRIAL_OK : TRIAL_FAIL;
   uint32_t nj = 0, a = a0, d = 0;
   double tau = 0.0;
   epv_block2 blk;
   blk.d0 = 0.0; blk.d1 = 0.0;
+  double u = u0;
   int outcome;
   for (;;) {
-    if ((d & 1u) == 0u) blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, t, d >> 1);
-    const double u = (d & 1u) ? blk.d1 : blk.d0;
-    ++d;
     tau += -epv_log(1.0 - u) / (a ? r1 : r0);
     if (!(tau < T)) { outcome = (a == end) ? TRIAL_OK : TRIAL_FAIL; break; }
     if (nj >= room) { outcome = TRIAL_OVERFLOW; break; }
     a ^= 1u;
-    if (STORE) dst[(uint64_t)nj * n] = tau + start_time;
+    if (nj < max_store) dst[(uint64_t)nj * stride] = tau + start_time;
     ++nj;
+    if ((d & 1u) == 0u) blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, t, d >> 1);
+    u = (d & 1u) ? blk.d1 : blk.d0;
+    ++d;
   }
   nj_out = nj;
   return outcome;
+}
+
+// exp(-x) bound for the shortcut above: float exp, shrunk; 0 (never taken) when x is
+// large enough that float accuracy is not guaranteed
+__device__ __forceinline__ double nojump_bound(double x) {
+  return x < 40.0 ? (double)__expf(-(float)x) * 0.9999 : 0.0;
 }
 
 // ------------------------------------------------ LDS staging of constants
@@ -209,11 +229,9 @@ __device__ __forceinline__ double gtp(double r0, double r1, double h, double den
 // holds the node's q).  When the lanes of a wave together need more records than the
 // pool has, the wave runs the update in several rounds over a prefix of its lanes.
 #define EPV_MH_THREADS 256
-
-__global__ __launch_bounds__(EPV_MH_THREADS) void epv_mh_phase_kernel(
+__global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
-    uint64_t first, uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t pool_entries,
-    unsigned long long *counters) {
+    uint64_t first, uint64_t last, uint32_t pool_entries, unsigned long long *counters) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   double *s_const = s_mem;                     // 20 + N doubles (padded to even)
   const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
@@ -249,8 +267,6 @@ __global__ __launch_bounds__(EPV_MH_THREADS) void epv_mh_phase_kernel(
   }
 
   bool pending = valid;
-  uint32_t n_coop = 0;
-  bool accepted = false, overflowed = false;
   while (__any(pending)) {
     const uint32_t want = pending ? need : 0u;
     const uint32_t incl = wave_incl_scan_u32(want);
@@ -313,7 +329,12 @@ __global__ __launch_bounds__(EPV_MH_THREADS) void epv_mh_phase_kernel(
         double *recq = my + (size_t)(off + K) * 4u;
         recq[0] = q0; recq[1] = q1;
         double n0 = q0, n1 = q1;
+#ifdef EPV_ABLATE_PRUNE
+        for (uint32_t kk = K; kk-- > 0u;) { double *rec = my + (size_t)(off + kk) * 4u; rec[0] = 0.5; rec[1] = 0.5; }
+        for (uint32_t kk = 0; kk-- > 0u;) {
+#else
         for (uint32_t kk = K; kk-- > 0u;) {
+#endif
           double *rec = my + (size_t)(off + kk) * 4u;
           const double len = rec[2];
           const uint32_t trip0 = (uint32_t)epv_d2u(rec[3]);
@@ -335,69 +356,59 @@ __global__ __launch_bounds__(EPV_MH_THREADS) void epv_mh_phase_kernel(
       }
     }
 
-    // ---- 3. downward sampling (:180-255) fused with proposal_prob of the current
-    //         path (:272-339); the rejection search is wave-cooperative
+    // ---- 3. downward sampling of the segment END STATES (:180-255) fused with
+    //         proposal_prob of the current path (:272-339).  The jump times inside the
+    //         segments do not influence any state or log-probability, so they are NOT
+    //         drawn here: a branch whose every segment keeps its state and provably
+    //         (run_trial's shortcut) has no jump in trial 1 is "clean" -- its proposal is
+    //         the empty jump list -- and every other (site, branch) pair is appended to a
+    //         compact task list for epv_mh_jumps_kernel, which runs the exact forward
+    //         rejection with dense lanes instead of making 64 lanes wait for 3.
     double log_prob = 0.0, orig_proposal = 0.0;
-    bool ovf = false;
+    unsigned long long dirty = 0ull;   // bit (node-1) & 63, flushed every 64 branches
     {
       uint32_t off = 0;
       const uint32_t root_state = run ? (uint32_t)(S.meta[((uint64_t)selM * B) * n + site] >> 7) : 0u;
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t b = node - 1u;
-        uint32_t K = 0;
-        uint32_t start_state = 0;
-        PathRef cur;
-        cur.j = nullptr; cur.nj = 0; cur.init = 0;
         if (run) {
           const uint32_t mL = S.meta[((uint64_t)selL * B + b) * n + site - 1];
           const uint32_t mR = S.meta[((uint64_t)selR * B + b) * n + site + 1];
-          K = (mL & 127u) + (mR & 127u) + 1u;
+          const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
           const uint32_t par = S.parent[node];
-          start_state = (par == 0u)
-                            ? root_state
-                            : (uint32_t)epv_d2u(regA[((size_t)par * 64u + lane) * 2u]);
-          cur = path_ref(S, selM, b, site);
-        }
-        double *dst_base = S.jumps + ((uint64_t)(selM ^ 1u) * B + b) * C * n + site;
-        uint32_t prev = start_state, cnt = 0;
-        double time_passed = 0.0;
-        // walk of the current path
-        uint32_t cs_start = cur.init, cs_end = cur.init, sj = 0, ej = 0;
-        double end_time = 0.0, lp = 0.0;
-        double cur_next = cur.nj ? cur.j[0] : EPV_INF;
-
-        const uint32_t kmax = wave_max_u32(K);
-        for (uint32_t k = 0; k < kmax; ++k) {
-          const bool on = run && k < K;
-          bool ok = true;
-          uint32_t sampled = 0;
-          double len = 0.0, r0 = 1.0, r1 = 1.0;
-          if (on) {
+          const uint32_t start_state =
+              (par == 0u) ? root_state : (uint32_t)epv_d2u(regA[((size_t)par * 64u + lane) * 2u]);
+          const PathRef cur = path_ref(S, selM, b, site);
+          uint32_t prev = start_state;
+          bool clean = true;
+          unsigned long long word = 0ull;
+          uint64_t *states = S.prop_states + ((uint64_t)b * n + site) * S.W;
+          // walk of the current path
+          uint32_t cs_start = cur.init, cs_end = cur.init, sj = 0, ej = 0;
+          double end_time = 0.0, lp = 0.0;
+          double cur_next = cur.nj ? cur.j[0] : EPV_INF;
+          for (uint32_t k = 0; k < K; ++k) {
             const double *rec = my + (size_t)(off + k) * 4u;
             const double pk0 = rec[0], pk1 = rec[1];
-            len = rec[2];
+            const double len = rec[2];
             const uint32_t trip0 = (uint32_t)epv_d2u(rec[3]);
             const double nxt0 = rec[4];  // p[k+1][0], or q[0] after the last segment
-            r0 = s_rates[trip0]; r1 = s_rates[trip0 | 2u];
+            const double r0 = s_rates[trip0], r1 = s_rates[trip0 | 2u];
             const double h = epv_exp(-len * (r0 + r1));
             const double denom = r0 + r1;
             // proposal: end state of the segment
             const double PT0 = gtp(r0, r1, h, denom, prev, 0u);
             const double p0 = PT0 * nxt0 / (prev ? pk1 : pk0);
-            const double u = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, 0u, 0u).d0;
-            sampled = (u > p0) ? 1u : 0u;
+            const epv_block2 sblk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, 0u, 0u);
+            const uint32_t sampled = (sblk.d0 > p0) ? 1u : 0u;
             log_prob += (sampled == 0u) ? epv_log(p0) : epv_log(1.0 - p0);
-            if (!ovf) {
-              // first trial inline, jumps stored speculatively behind the committed ones
-              uint32_t njt;
-              const int oc = run_trial<true>(seed_lo, seed_hi, gsite, sweep, node, k, 1u, prev,
-                                             sampled, len, r0, r1, C - cnt,
-                                             dst_base + (uint64_t)cnt * n, n, time_passed, njt);
-              if (oc == TRIAL_OK) cnt += njt;
-              else if (oc == TRIAL_OVERFLOW) ovf = true;
-              else ok = false;
-            }
             log_prob -= epv_log(gtp(r0, r1, h, denom, prev, sampled));
+            // trial 1's first draw is the other half of the same Philox block
+            clean = clean && (sampled == prev) &&
+                    (1.0 - sblk.d1 < nojump_bound(len * (prev ? r1 : r0)));
+            word |= (unsigned long long)sampled << (k & 63u);
+            if ((k & 63u) == 63u) { states[k >> 6] = word; word = 0ull; }
+#ifndef EPV_ABLATE_CURPATH
             // current path: where does it stand at the end of this segment
             end_time += len;
             while (ej < cur.nj && cur_next < end_time) {
@@ -411,96 +422,306 @@ __global__ __launch_bounds__(EPV_MH_THREADS) void epv_mh_phase_kernel(
             lp += (cs_end == 0u) ? epv_log(p0c) : epv_log(1.0 - p0c);
             sj = ej;
             cs_start = cs_end;
-          }
-          // wave-cooperative search for the first non-failing trial t >= 2: all 64
-          // lanes evaluate 64 consecutive trials of ONE lane's segment at a time
-          unsigned long long todo = __ballot(on && !ok);
-          while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            const uint32_t l_gsite = __shfl(gsite, leader);
-            const uint32_t l_prev = __shfl(prev, leader);
-            const uint32_t l_end = __shfl(sampled, leader);
-            const uint32_t l_room = __shfl(C - cnt, leader);
-            const double l_len = shfl_f64(len, leader);
-            const double l_r0 = shfl_f64(r0, leader);
-            const double l_r1 = shfl_f64(r1, leader);
-            uint32_t tbase = 2u, tstar = 0u;
-            for (;;) {
-              uint32_t njt;
-              const int oc = run_trial<false>(seed_lo, seed_hi, l_gsite, sweep, node, k,
-                                              tbase + (uint32_t)lane, l_prev, l_end, l_len, l_r0,
-                                              l_r1, l_room, nullptr, n, 0.0, njt);
-              const unsigned long long hit = __ballot(oc != TRIAL_FAIL);
-              if (hit) { tstar = tbase + (uint32_t)(__ffsll((long long)hit) - 1); break; }
-              tbase += 64u;
-            }
-            if (lane == leader) {
-              uint32_t njt;
-              const int oc = run_trial<true>(seed_lo, seed_hi, gsite, sweep, node, k, tstar, prev,
-                                             sampled, len, r0, r1, C - cnt,
-                                             dst_base + (uint64_t)cnt * n, n, time_passed, njt);
-              if (oc == TRIAL_OK) cnt += njt;
-              else ovf = true;
-              ++n_coop;
-            }
-          }
-          if (on) {
-            time_passed += len;
+#endif
             prev = sampled;
           }
-        }
-        if (run) {
-          if (ovf) cnt = (start_state ^ prev) & 1u;  // keep parity for the children
-          S.meta[((uint64_t)(selM ^ 1u) * B + b) * n + site] = (uint8_t)((start_state << 7) | cnt);
+          if (K & 63u) states[(K - 1u) >> 6] = word;
+          // proposal so far: no jumps; epv_mh_jumps_kernel fills dirty branches in
+          S.meta[((uint64_t)(selM ^ 1u) * B + b) * n + site] = (uint8_t)(start_state << 7);
           regA[((size_t)node * 64u + lane) * 2u] = epv_u2d((uint64_t)prev);  // proposal end state
           orig_proposal += lp;
           off += K + 1u;
+          if (!clean) dirty |= 1ull << (b & 63u);
+        }
+        // flush the dirty (site, branch) pairs of the last <= 64 branches: ONE atomic per
+        // wave reserves the slots, the lanes fill them in
+        if ((b & 63u) == 63u || node + 1u == S.N) {
+          const uint32_t mine = (uint32_t)__popcll(dirty);
+          const uint32_t incl_t = wave_incl_scan_u32(mine);
+          const uint32_t total = __shfl(incl_t, 63);
+          if (total) {
+            unsigned long long base = 0ull;
+            if (lane == 0) base = atomicAdd(&counters[EPV_CNT_TASKS], (unsigned long long)total);
+            base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0) << 32) |
+                   (unsigned long long)__shfl((uint32_t)base, 0);
+            unsigned long long slot = base + (incl_t - mine);
+            unsigned long long d = dirty;
+            while (d) {
+              const uint32_t bit = (uint32_t)(__ffsll((long long)d) - 1);
+              d &= d - 1ull;
+              S.tasks[slot++] = ((unsigned long long)((b & ~63u) + bit) << 40) | site;
+            }
+          }
+          dirty = 0ull;
         }
       }
     }
 
-    // ---- 4. acceptance (log_accept_rate :396-433, Metropolis_Hastings_site :510-533)
+    // ---- hand-over to epv_mh_accept_kernel: q(old) - q(new) and the overflow flag
     if (run) {
-      double llh_l = S.tri[site - 1];
-      double llh_m = S.tri[site];
-      double llh_r = S.tri[site + 1];
-      double llr = orig_proposal - log_prob;
-      const double llh_l_orig = llh_l, llh_r_orig = llh_r;
-      if (!ovf) {
-        const uint32_t selP = selM ^ 1u;
-        const uint64_t g = S.g0 + site;
-        if (g > 1u)
-          llh_l = triple_llh(S, s_const, s_blen, S.sel[site - 2], site - 2, selL, site - 1, selP, site);
-        llh_m = triple_llh(S, s_const, s_blen, selL, site - 1, selP, site, selR, site + 1);
-        if (g < S.n_global - 2u)
-          llh_r = triple_llh(S, s_const, s_blen, selP, site, selR, site + 1, S.sel[site + 2], site + 2);
-      }
-      llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
-      const double u = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, 0u, 0u, 0u, 0u).d0;
-      bool acc = (llr >= 0.0) || (u < epv_exp(llr));
-      if (ovf) { acc = false; overflowed = true; }
-      if (acc) {
-        S.sel[site] = (uint8_t)(selM ^ 1u);
-        S.tri[site - 1] = llh_l;
-        S.tri[site] = llh_m;
-        S.tri[site + 1] = llh_r;
-        // redundant updates of halo columns (site-sharded runs) are not counted
-        accepted = site >= own_first && site <= own_last;
-      }
+      S.prop_llr[site] = orig_proposal - log_prob;
+      S.prop_flag[site] = 0u;
       pending = false;
     }
   }
 
-  // ---- counters: one atomic per wave and kind
+}
+
+// =========================================================================
+//  exact forward rejection (EndCondSampling.cpp:466-509) for the dirty (site, branch)
+//  pairs listed by epv_mh_propose_kernel: ONE LANE PER PAIR, so lanes are dense.  The
+//  lane re-derives the branch's segments from the neighbours' jump planes (2-way merge,
+//  nothing was stored), reads the sampled end states from the bit words, and for every
+//  segment runs trials t = 1, 2, ... until one does not fail, appending the accepted
+//  jump times to the site's proposal buffer.  Random-access Philox makes this the same
+//  numbers the oracle draws inside its single per-site function.
+// =========================================================================
+#define EPV_TJ 4u          /* jumps a search lane hands over through LDS */
+#define EPV_INLINE_TRIALS 4u /* trials a lane runs by itself before asking the wave for help */
+
+__global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
+                                                           uint32_t seed_hi, uint32_t sweep,
+                                                           unsigned long long *counters) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  // per-wave cooperative-search area: task slots by rank and per-lane trial results
+  __shared__ double c_len_[4][64], c_r0_[4][64], c_r1_[4][64], c_tj_[4][64 * EPV_TJ];
+  __shared__ uint32_t c_misc_[4][64], c_gsite_[4][64], c_tbase_[4][64], c_nk_[4][64], c_res_[4][64];
+  stage_constants(S, s_mem);
+  const double *s_rates = s_mem, *s_blen = s_mem + 20;
+  const uint32_t wave = threadIdx.x >> 6;
+  const int lane = epv_lane();
+  double *c_len = c_len_[wave], *c_r0 = c_r0_[wave], *c_r1 = c_r1_[wave], *c_tj = c_tj_[wave];
+  uint32_t *c_misc = c_misc_[wave], *c_gsite = c_gsite_[wave], *c_tbase = c_tbase_[wave],
+           *c_nk = c_nk_[wave], *c_res = c_res_[wave];
+  const unsigned long long n_tasks = counters[EPV_CNT_TASKS];
+  const uint64_t n = S.n;
+  const uint32_t B = S.B, C = S.C;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  // every wave makes the same number of passes so that the cooperative parts stay
+  // wave-uniform; lanes without a task idle as helpers
+  for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < n_tasks;
+       base += stride) {
+    const unsigned long long ti = base + threadIdx.x;
+    bool active = ti < n_tasks;
+    uint64_t site = 0;
+    uint32_t b = 0, node = 1, gsite = 0, start_state = 0, prev = 0, cnt = 0, k = 0;
+    uint32_t trip0 = 0, i = 0, j = 0;
+    PathRef L, R;
+    L.j = R.j = nullptr; L.nj = R.nj = 0; L.init = R.init = 0;
+    const uint64_t *states = nullptr;
+    uint8_t *meta = nullptr;
+    double *dst = nullptr;
+    double seg_start = 0.0;    // time of the previous neighbour jump (Segment.cpp's prev_time)
+    double time_passed = 0.0;  // running SUM of segment lengths (SingleSiteSampler.cpp:218)
+    double tl = EPV_INF, tr = EPV_INF;
+    unsigned long long word = 0ull;
+    bool ovf = false;
+    if (active) {
+      const unsigned long long task = S.tasks[ti];
+      site = task & 0xffffffffffull;
+      b = (uint32_t)(task >> 40);
+      node = b + 1u;
+      gsite = (uint32_t)(S.g0 + site);
+      const uint32_t selL = S.sel[site - 1], selP = S.sel[site] ^ 1u, selR = S.sel[site + 1];
+      L = path_ref(S, selL, b, site - 1);
+      R = path_ref(S, selR, b, site + 1);
+      states = S.prop_states + ((uint64_t)b * n + site) * S.W;
+      meta = S.meta + ((uint64_t)selP * B + b) * n + site;
+      dst = S.jumps + ((uint64_t)selP * B + b) * C * n + site;
+      start_state = (uint32_t)(*meta >> 7);
+      prev = start_state;
+      trip0 = 4u * L.init + R.init;
+      tl = L.nj ? L.j[0] : EPV_INF;
+      tr = R.nj ? R.j[0] : EPV_INF;
+      word = states[0];
+    }
+    // one segment per active lane and iteration, in Segment.cpp:35-79's merge order
+    while (__any(active)) {
+      bool pend = false, last = false, take_left = false;
+      uint32_t sampled = 0, tbase = EPV_INLINE_TRIALS + 1u;
+      double len = 0.0, r0 = 1.0, r1 = 1.0, seg_end = 0.0;
+      if (active) {
+        last = !(i < L.nj || j < R.nj);
+        take_left = tl < tr;
+        seg_end = last ? s_blen[node] : (take_left ? tl : tr);
+        len = seg_end - seg_start;
+        sampled = (uint32_t)(word >> (k & 63u)) & 1u;
+        r0 = s_rates[trip0]; r1 = s_rates[trip0 | 2u];
+        if (!ovf) {
+          const double b0 = nojump_bound(len * r0), b1 = nojump_bound(len * r1);
+          uint32_t njt;
+          // trial 1: first draw = second half of the segment's state block
+          int oc = run_trial(seed_lo, seed_hi, gsite, sweep, node, k, 1u,
+                             epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, 0u, 0u).d1, prev,
+                             sampled, len, r0, r1, b0, b1, C - cnt, dst + (uint64_t)cnt * n, n,
+                             0xffffffffu, time_passed, njt);
+          for (uint32_t t = 2u; oc == TRIAL_FAIL && t <= EPV_INLINE_TRIALS; ++t) {
+            const epv_block2 fb = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, t >> 1,
+                                                  EPV_FIRST_DRAW_BLOCK);
+            oc = run_trial(seed_lo, seed_hi, gsite, sweep, node, k, t, (t & 1u) ? fb.d1 : fb.d0, prev,
+                           sampled, len, r0, r1, b0, b1, C - cnt, dst + (uint64_t)cnt * n, n,
+                           0xffffffffu, time_passed, njt);
+          }
+          if (oc == TRIAL_OK) cnt += njt;
+          else if (oc == TRIAL_OVERFLOW) ovf = true;
+          else pend = true;
+        }
+      }
+      // Wave-cooperative search for the first non-failing trial t > EPV_INLINE_TRIALS of
+      // every still-pending lane.  The P pending tasks share the 64 lanes: the task of rank
+      // r gets the G = 2^floor(log2(64/P)) lanes [rG, rG+G), which evaluate G consecutive
+      // trials of that ONE segment (random-access RNG); the lowest non-failing trial wins
+      // and hands its jump times over through LDS; tasks that found none advance their
+      // window by G.  A leaf that forces a flip on a short branch needs ~1/P(a->b) trials
+      // (hundreds for the slowest context); this turns that serial tail into a few
+      // full-width rounds.  Identical to the sequential "first non-failing t" whatever P, G.
+      unsigned long long todo = __ballot(pend);
+      while (todo) {
+        const uint32_t P = (uint32_t)__popcll(todo);
+        const uint32_t lg = 31u - (uint32_t)__clz((int)(64u / P));
+        const uint32_t G = 1u << lg;
+        const uint32_t rank = (uint32_t)__popcll(todo & ((1ull << lane) - 1ull));
+        if (pend) {
+          c_len[rank] = len; c_r0[rank] = r0; c_r1[rank] = r1;
+          c_misc[rank] = prev | (sampled << 1) | ((C - cnt) << 8);
+          c_gsite[rank] = gsite;
+          c_tbase[rank] = tbase;
+          c_nk[rank] = (node << 12) | k;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t tj = (uint32_t)lane >> lg, tr_ = (uint32_t)lane & (G - 1u);
+        int oc = TRIAL_FAIL;
+        if (tj < P) {
+          const uint32_t misc = c_misc[tj], nk = c_nk[tj];
+          const double t_len = c_len[tj], t_r0 = c_r0[tj], t_r1 = c_r1[tj];
+          const uint32_t t = c_tbase[tj] + tr_, t_site = c_gsite[tj];
+          const epv_block2 fb = epv_keyed_block(seed_lo, seed_hi, t_site, sweep, nk >> 12, nk & 4095u,
+                                                t >> 1, EPV_FIRST_DRAW_BLOCK);
+          uint32_t njt;
+          oc = run_trial(seed_lo, seed_hi, t_site, sweep, nk >> 12, nk & 4095u, t,
+                         (t & 1u) ? fb.d1 : fb.d0, misc & 1u, (misc >> 1) & 1u, t_len, t_r0, t_r1,
+                         nojump_bound(t_len * t_r0), nojump_bound(t_len * t_r1), misc >> 8,
+                         c_tj + (size_t)lane * EPV_TJ, 1u, EPV_TJ, 0.0, njt);
+          c_res[lane] = (uint32_t)oc | (njt << 8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long hit = __ballot(oc != TRIAL_FAIL);
+        if (pend) {
+          const unsigned long long mine =
+              (hit >> (rank * G)) & (G == 64u ? ~0ull : ((1ull << G) - 1ull));
+          if (mine) {
+            const uint32_t wi = (uint32_t)(__ffsll((long long)mine) - 1);
+            const uint32_t w = rank * G + wi;
+            const uint32_t res = c_res[w], njt = res >> 8;
+            if ((res & 0xffu) == (uint32_t)TRIAL_OK) {
+              double *d2 = dst + (uint64_t)cnt * n;
+              if (njt <= EPV_TJ) {
+                for (uint32_t q = 0; q < njt; ++q)
+                  d2[(uint64_t)q * n] = c_tj[(size_t)w * EPV_TJ + q] + time_passed;
+              } else {  // rare: more jumps than the LDS hand-over holds -> replay the winner
+                const uint32_t tw = tbase + wi;
+                const epv_block2 fb = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, tw >> 1,
+                                                      EPV_FIRST_DRAW_BLOCK);
+                uint32_t nj2;
+                run_trial(seed_lo, seed_hi, gsite, sweep, node, k, tw, (tw & 1u) ? fb.d1 : fb.d0, prev,
+                          sampled, len, r0, r1, 0.0, 0.0, C - cnt, d2, n, 0xffffffffu, time_passed, nj2);
+              }
+              cnt += njt;
+            } else {
+              ovf = true;
+            }
+            pend = false;
+          } else {
+            tbase += G;
+          }
+        }
+        todo = __ballot(pend);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (active) {
+        prev = sampled;
+        time_passed += len;
+        if (last) {
+          if (ovf) {
+            cnt = (start_state ^ prev) & 1u;  // keep the end-state parity; the proposal is rejected
+            S.prop_flag[site] = 1u;
+          }
+          *meta = (uint8_t)((start_state << 7) | cnt);
+          active = false;
+        } else {
+          if (take_left) { trip0 ^= 4u; ++i; tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF; }
+          else { trip0 ^= 1u; ++j; tr = j < R.nj ? R.j[(uint64_t)j * n] : EPV_INF; }
+          seg_start = seg_end;
+          ++k;
+          if ((k & 63u) == 0u) word = states[k >> 6];
+        }
+      }
+    }
+  }
+}
+
+// =========================================================================
+//  acceptance (log_accept_rate SingleSiteSampler.cpp:396-433, Metropolis_Hastings_site
+//  :510-533): one lane per site of the colour, after epv_mh_propose_kernel has written
+//  the proposal into the site's other buffer.  No record pool here, so this part runs
+//  at full occupancy.
+// =========================================================================
+__global__ __launch_bounds__(256) void epv_mh_accept_kernel(
+    EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
+    uint64_t first, uint64_t last, uint64_t own_first, uint64_t own_last,
+    unsigned long long *counters) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  stage_constants(S, s_mem);
+  const double *s_const = s_mem, *s_blen = s_mem + 20;
+  const int lane = epv_lane();
+  const uint64_t gfirst = S.g0 + first;
+  const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t site = s0 + 3u * tid;
+  bool accepted = false, overflowed = false;
+  if (site <= last) {
+    const uint32_t selL = S.sel[site - 1], selM = S.sel[site], selR = S.sel[site + 1];
+    const uint32_t gsite = (uint32_t)(S.g0 + site);
+    const bool ovf = S.prop_flag[site] != 0;
+    double llh_l = S.tri[site - 1];
+    double llh_m = S.tri[site];
+    double llh_r = S.tri[site + 1];
+    double llr = S.prop_llr[site];
+    const double llh_l_orig = llh_l, llh_r_orig = llh_r;
+    if (!ovf) {
+      const uint32_t selP = selM ^ 1u;
+      const uint64_t g = S.g0 + site;
+      if (g > 1u)
+        llh_l = triple_llh(S, s_const, s_blen, S.sel[site - 2], site - 2, selL, site - 1, selP, site);
+      llh_m = triple_llh(S, s_const, s_blen, selL, site - 1, selP, site, selR, site + 1);
+      if (g < S.n_global - 2u)
+        llh_r = triple_llh(S, s_const, s_blen, selP, site, selR, site + 1, S.sel[site + 2], site + 2);
+    }
+    llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
+    const double u = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, 0u, 0u, 0u, 0u).d0;
+    bool acc = (llr >= 0.0) || (u < epv_exp(llr));
+    if (ovf) { acc = false; overflowed = true; }
+    if (acc) {
+      S.sel[site] = (uint8_t)(selM ^ 1u);
+      S.tri[site - 1] = llh_l;
+      S.tri[site] = llh_m;
+      S.tri[site + 1] = llh_r;
+      // redundant updates of halo columns (site-sharded runs) are not counted
+      accepted = site >= own_first && site <= own_last;
+    }
+  }
   const unsigned long long am = __ballot(accepted), om = __ballot(overflowed);
-  uint32_t coop = n_coop;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) coop += __shfl_xor(coop, d);
   if (lane == 0) {
     if (am) atomicAdd(&counters[EPV_CNT_ACCEPT], (unsigned long long)__popcll(am));
     if (om) atomicAdd(&counters[EPV_CNT_OVERFLOW], (unsigned long long)__popcll(om));
-    if (coop) atomicAdd(&counters[EPV_CNT_COOP], (unsigned long long)coop);
+  }
+  // the task list of this phase has been consumed (stream order): fold its length into
+  // the running total and clear it for the next propose kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    counters[EPV_CNT_COOP] += counters[EPV_CNT_TASKS];
+    counters[EPV_CNT_TASKS] = 0ull;
   }
 }
 

@@ -14,9 +14,13 @@
 //   c3 = branch<<20 | segment<<8 | block            (12 / 12 / 8 bits)
 // A block yields two doubles in [0,1): d0 from words (1:0), d1 from (3:2), each the
 // top 53 bits of the 64-bit pair times 2^-53.
-//   accept uniform          : (b=0,k=0,t=0,blk=0).d0   (SingleSiteSampler.cpp:520-521)
-//   segment end-state unif. : (b,k,t=0,blk=0).d0       (SingleSiteSampler.cpp:206)
-//   trial t>=1, draw d      : (b,k,t,blk=d>>1).d[d&1]  (EndCondSampling.cpp:470-474)
+//   accept uniform            : (b=0,k=0,t=0,blk=0).d0      (SingleSiteSampler.cpp:520-521)
+//   segment end-state uniform : (b,k,t=0,blk=0).d0          (SingleSiteSampler.cpp:206)
+//   trial 1, first draw       : (b,k,t=0,blk=0).d1          (same block as the line above)
+//   trial t>=2, first draw    : (b,k,t>>1,blk=255).d[t&1]   (trials 2m, 2m+1 share a block)
+//   trial t>=1, draw d>=1     : (b,k,t,blk=(d-1)>>1).d[(d-1)&1]   (EndCondSampling.cpp:470-474)
+// Most trials end at their first draw (no jump inside the segment), so the common case
+// costs ONE Philox block per segment.
 #ifndef EPV_PHILOX_H
 #define EPV_PHILOX_H
 
@@ -26,6 +30,7 @@
 #define EPV_PHILOX_M1 0xCD9E8D57u
 #define EPV_PHILOX_W0 0x9E3779B9u
 #define EPV_PHILOX_W1 0xBB67AE85u
+#define EPV_FIRST_DRAW_BLOCK 255u
 
 struct epv_block2 {
   double d0, d1;

@@ -236,9 +236,21 @@ static inline void rng_trial_begin(orc_rng *g, uint32_t b, uint32_t k, uint32_t 
 }
 static inline double rng_trial_canonical(orc_rng *g) {
   if (g->st->rng_mode == ORC_RNG_MT) return orc_mt_canonical(&g->st->mt);
-  if ((g->d & 1u) == 0)
-    orc_keyed_block(g->st->seed, g->site, g->sweep, g->b, g->k, g->t, g->d >> 1, g->blk);
-  return g->blk[g->d++ & 1u];
+  double blk[2];
+  const uint32_t d = g->d++;
+  if (d == 0) {
+    /* first draw: trial 1 shares the segment's block (its d1); trials 2m, 2m+1 share
+     * block (t = m, blk = 255) */
+    if (g->t == 1) {
+      orc_keyed_block(g->st->seed, g->site, g->sweep, g->b, g->k, 0, 0, blk);
+      return blk[1];
+    }
+    orc_keyed_block(g->st->seed, g->site, g->sweep, g->b, g->k, g->t >> 1, ORC_FIRST_DRAW_BLOCK, blk);
+    return blk[g->t & 1u];
+  }
+  if (((d - 1u) & 1u) == 0)
+    orc_keyed_block(g->st->seed, g->site, g->sweep, g->b, g->k, g->t, (d - 1u) >> 1, g->blk);
+  return g->blk[(d - 1u) & 1u];
 }
 
 /* ------------------------------------------------ end-conditioned sampling */

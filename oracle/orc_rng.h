@@ -92,10 +92,15 @@ static inline void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2
  *   c3 = branch<<20 | segment<<8 | block          (12 / 12 / 8 bits)
  * A block yields two doubles in [0,1): d0 from words (1:0), d1 from (3:2),
  * each the top 53 bits of the 64-bit word pair times 2^-53.
- *   accept uniform          : (b=0,k=0,t=0,blk=0).d0
- *   segment end-state unif. : (b,k,t=0,blk=0).d0
- *   trial t>=1, draw d      : (b,k,t,blk=d>>1).d[d&1]
+ *   accept uniform              : (b=0,k=0,t=0,blk=0).d0
+ *   segment end-state uniform   : (b,k,t=0,blk=0).d0
+ *   trial 1, first draw         : (b,k,t=0,blk=0).d1        (same block as the line above)
+ *   trial t>=2, first draw      : (b,k,t>>1,blk=255).d[t&1]  (trials 2m, 2m+1 share a block)
+ *   trial t>=1, draw d>=1       : (b,k,t,blk=(d-1)>>1).d[(d-1)&1]
+ * Most trials end at their first draw (no jump inside the segment), so the common
+ * case costs one Philox block per segment.
  */
+#define ORC_FIRST_DRAW_BLOCK 255u
 #define ORC_MAX_BRANCH 4095u
 #define ORC_MAX_SEG 4095u
 #define ORC_MAX_BLOCK 255u
