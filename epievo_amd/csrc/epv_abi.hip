@@ -86,14 +86,15 @@ size_t const_lds_bytes(uint32_t N) { return (size_t)((20u + N + 1u) & ~1u) * 8u;
 int plan_mh(epv_ctx *c) {
   const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
   const uint64_t worst = (uint64_t)B * (2u * C + 2u);
-  const size_t fixed = const_lds_bytes(N) + (size_t)N * 128u * 8u;
-  if (fixed + worst * 32u > 160u * 1024u)
+  // per wave: node table N*64 u32 (rounded to 16 B) + pool of 16-byte records
+  const size_t fixed = const_lds_bytes(N) + (((size_t)N * 64u * 4u + 15u) & ~(size_t)15u);
+  if (fixed + worst * 16u > 160u * 1024u)
     return fail(c, EPV_ERR_ARG, "tree/capacity too large for the 160 KiB LDS record pool");
   // typical demand of 64 lanes: B * (2 kbar + 2) records each, with a 30 % margin
   const uint64_t typical = (uint64_t)(64.0 * B * (2.0 * c->kbar + 2.0) * 1.3) + 32u;
-  const uint64_t max_fit = (160u * 1024u - fixed) / 32u;
+  const uint64_t max_fit = (160u * 1024u - fixed) / 16u;
   const uint64_t pool = std::min<uint64_t>(std::max<uint64_t>(worst, typical), max_fit);
-  const size_t lds = fixed + (size_t)pool * 32u;
+  const size_t lds = fixed + (size_t)pool * 16u;
   c->mh_threads = 64;
   c->pool_entries = (uint32_t)pool;
   c->mh_lds = lds;

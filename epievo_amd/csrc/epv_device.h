@@ -1,7 +1,7 @@
 // epv_device.h -- device-side data layout shared by the kernels and the ABI glue.
 //
 // HBM layout (SoA, "jump times packed as SoA for coalesced access"):
-//   meta [2][B][n]     u8   bit7 = Path::init_state, bits0-6 = number of jumps
+//   meta [2][n][B]     u8   bit7 = Path::init_state, bits0-6 = number of jumps (site-major)
 //   jumps[2][B][C][n]  f64  jump k of (buffer, branch, site) at ((buf*B+b)*C+k)*n+site
 //   sel  [n]           u8   which of the two buffers holds the CURRENT path of a site
 //   tri  [n]           f64  cached complete-data log-likelihood of the triple centred

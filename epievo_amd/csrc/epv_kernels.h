@@ -62,6 +62,11 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
 }
 
 // ------------------------------------------------------------------ path access
+// meta is SITE-major: the B bytes of one site's column sit together, so the branches of a
+// column come out of one cache line (one dword for tree.nwk's four branches)
+__device__ __forceinline__ uint64_t meta_idx(const EpvDev &S, uint32_t buf, uint32_t b, uint64_t site) {
+  return ((uint64_t)buf * S.n + site) * S.B + b;
+}
 struct PathRef {
   const double *j;  // jump k lives at j[k * n]
   uint32_t nj;
@@ -70,7 +75,7 @@ struct PathRef {
 __device__ __forceinline__ PathRef path_ref(const EpvDev &S, uint32_t buf, uint32_t b,
                                             uint64_t site) {
   const uint64_t plane = (uint64_t)buf * S.B + b;
-  const uint8_t m = S.meta[plane * S.n + site];
+  const uint8_t m = S.meta[meta_idx(S, buf, b, site)];
   PathRef p;
   p.j = S.jumps + plane * S.C * S.n + site;
   p.nj = m & 127u;
@@ -203,6 +208,51 @@ __device__ __forceinline__ double nojump_bound(double x) {
   return x < 40.0 ? (double)__expf(-(float)x) * 0.9999 : 0.0;
 }
 
+// First draw of trial t of segment (node,k) -- see the address table in epv_philox.h
+__device__ __forceinline__ double first_draw(uint32_t seed_lo, uint32_t seed_hi, uint32_t gsite,
+                                             uint32_t sweep, uint32_t node, uint32_t k, uint32_t t) {
+  if (t == 1u) return epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, 0u, 0u).d1;
+  const epv_block2 fb = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, t >> 1,
+                                        EPV_FIRST_DRAW_BLOCK);
+  return (t & 1u) ? fb.d1 : fb.d0;
+}
+
+// Evaluate trials t0 .. t0+W-1 of one segment IN ORDER and return the first one that does
+// not fail (its index in t_out), or TRIAL_FAIL when all W fail.  Two-level to keep the
+// lanes of a wave together: a cheap scan classifies each trial by its first draw alone
+// (no jump inside the segment: success if the end state equals the start state, failure
+// otherwise -- exact thanks to run_trial's guard band), and only a trial that does jump
+// is evaluated exactly.  On a short branch ~95 % of trials never leave the scan.
+__device__ __forceinline__ int scan_trials(uint32_t seed_lo, uint32_t seed_hi, uint32_t gsite,
+                                           uint32_t sweep, uint32_t node, uint32_t k, uint32_t t0,
+                                           uint32_t W, uint32_t a0, uint32_t end, double T, double r0,
+                                           double r1, uint32_t room, double *dst, uint64_t stride,
+                                           uint32_t max_store, double start_time, uint32_t &t_out,
+                                           uint32_t &nj_out) {
+  const double bound = nojump_bound(T * (a0 ? r1 : r0));
+  uint32_t t = t0;
+  const uint32_t t_end = t0 + W;
+  nj_out = 0;
+  for (;;) {
+    double u = 0.0;
+    bool cand = false;
+    for (; t < t_end; ++t) {
+      u = first_draw(seed_lo, seed_hi, gsite, sweep, node, k, t);
+      if (1.0 - u < bound) {              // provably no jump in this trial
+        if (a0 == end) { t_out = t; nj_out = 0; return TRIAL_OK; }
+      } else {
+        cand = true;
+        break;
+      }
+    }
+    if (!cand) return TRIAL_FAIL;
+    const int oc = run_trial(seed_lo, seed_hi, gsite, sweep, node, k, t, u, a0, end, T, r0, r1, 0.0,
+                             0.0, room, dst, stride, max_store, start_time, nj_out);
+    if (oc != TRIAL_FAIL) { t_out = t; return oc; }
+    ++t;
+  }
+}
+
 // ------------------------------------------------ LDS staging of constants
 // layout (doubles): [0..19] model (rates, log_rates, T), [20 .. 20+N) branch lengths
 __device__ __forceinline__ void stage_constants(const EpvDev &S, double *s_const) {
@@ -221,15 +271,21 @@ __device__ __forceinline__ double gtp(double r0, double r1, double h, double den
 }
 
 // =========================================================================
-//  The Metropolis-Hastings colour-phase kernel
+//  Metropolis-Hastings colour phase, part 1: the proposal's segment end states
 // =========================================================================
-// Per-wave LDS: regA[N][64][2] doubles (per-node slot of every lane) followed by a
-// pool of `pool_entries` 32-byte segment records {p0, p1, len, trip0} handed out to the
-// lanes by a wave prefix sum (a branch with K segments uses K+1 records; the extra one
-// holds the node's q).  When the lanes of a wave together need more records than the
-// pool has, the wave runs the update in several rounds over a prefix of its lanes.
+// One lane per site.  Per-wave LDS: node table regA[N][64] u32 (record offset of the
+// branch above the node | proposal end state << 31) followed by a pool of
+// `pool_entries` 16-byte records {p0, p1} (Felsenstein partials at the top of each
+// segment) handed out to the lanes by a wave prefix sum; a branch with K segments uses
+// K+1 records, the extra one holding the node's q.  Segment lengths and contexts are
+// NOT stored: both passes re-derive them by merging the neighbours' jump planes on the
+// fly (backward in the pruning pass, forward in the sampling pass), which keeps the
+// pool small enough for ~12 waves per CU.  When the lanes of a wave together need more
+// records than the pool has, the wave runs the update in several rounds over a prefix of
+// its lanes.
 #define EPV_MH_THREADS 256
-__global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
+
+__global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
     uint64_t first, uint64_t last, uint32_t pool_entries, unsigned long long *counters) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
@@ -237,10 +293,10 @@ __global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
   const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
   const uint32_t wave = threadIdx.x >> 6;
   const int lane = epv_lane();
-  const uint32_t regA_dbl = S.N * 128u;        // N * 64 lanes * 2
-  const uint32_t wave_dbl = regA_dbl + pool_entries * 4u;
-  double *regA = s_mem + const_dbl + (size_t)wave * wave_dbl;
-  double *pool = regA + regA_dbl;
+  const uint32_t regA_dbl = (S.N * 64u + 1u) / 2u;   // N * 64 u32
+  const uint32_t wave_dbl = ((regA_dbl + 1u) & ~1u) + pool_entries * 2u;
+  uint32_t *regA = reinterpret_cast<uint32_t *>(s_mem + const_dbl + (size_t)wave * wave_dbl);
+  double *pool = s_mem + const_dbl + (size_t)wave * wave_dbl + ((regA_dbl + 1u) & ~1u);
   stage_constants(S, s_const);
   const double *s_rates = s_const;
   const double *s_blen = s_const + 20;
@@ -252,7 +308,7 @@ __global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
   const uint64_t site = s0 + 3u * tid;
   const bool valid = site <= last;
   const uint64_t n = S.n;
-  const uint32_t B = S.B, C = S.C;
+  const uint32_t B = S.B;
   const uint32_t gsite = (uint32_t)(S.g0 + site);
 
   uint32_t selL = 0, selM = 0, selR = 0;
@@ -260,8 +316,8 @@ __global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
   if (valid) {
     selL = S.sel[site - 1]; selM = S.sel[site]; selR = S.sel[site + 1];
     for (uint32_t b = 0; b < B; ++b) {
-      const uint32_t mL = S.meta[((uint64_t)selL * B + b) * n + site - 1];
-      const uint32_t mR = S.meta[((uint64_t)selR * B + b) * n + site + 1];
+      const uint32_t mL = S.meta[meta_idx(S, selL, b, site - 1)];
+      const uint32_t mR = S.meta[meta_idx(S, selR, b, site + 1)];
       need += (mL & 127u) + (mR & 127u) + 2u;  // K segments + 1 record for q
     }
   }
@@ -271,73 +327,46 @@ __global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
     const uint32_t want = pending ? need : 0u;
     const uint32_t incl = wave_incl_scan_u32(want);
     const bool run = pending && incl <= pool_entries;
-    double *my = pool + (size_t)(incl - want) * 4u;  // this lane's records
+    double *my = pool + (size_t)(incl - want) * 2u;  // this lane's records
 
-    // ---- 1. segments (Segment.cpp:35-79) -> records {.,.,len,trip0}
-    if (run) {
-      uint32_t off = 0;
-      for (uint32_t b = 0; b < B; ++b) {
-        const PathRef L = path_ref(S, selL, b, site - 1), R = path_ref(S, selR, b, site + 1);
-        uint32_t trip0 = 4u * L.init + R.init;
-        double prev = 0.0;
-        uint32_t i = 0, j = 0;
-        double tl = L.nj ? L.j[0] : EPV_INF, tr = R.nj ? R.j[0] : EPV_INF;
-        while (i < L.nj || j < R.nj) {
-          double *rec = my + (size_t)off * 4u;
-          // a left jump is taken only when strictly earlier than the right one;
-          // exhausted lists carry +inf so the tails fall out of the same test
-          if (tl < tr) {
-            rec[2] = tl - prev; rec[3] = epv_u2d(trip0);
-            trip0 ^= 4u; prev = tl; ++i;
-            tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF;
-          } else {
-            rec[2] = tr - prev; rec[3] = epv_u2d(trip0);
-            trip0 ^= 1u; prev = tr; ++j;
-            tr = j < R.nj ? R.j[(uint64_t)j * n] : EPV_INF;
-          }
-          ++off;
-        }
-        double *rec = my + (size_t)off * 4u;
-        rec[2] = s_blen[b + 1] - prev; rec[3] = epv_u2d(trip0);
-        off += 2u;  // last segment + the q record
-      }
-    }
-
-    // ---- 2. pruning, reverse pre-order (SingleSiteSampler.cpp:116-157)
+    // ---- 1. pruning, reverse pre-order (SingleSiteSampler.cpp:116-157) over segments
+    //         re-derived backwards from the neighbours' jumps (Segment.cpp:35-79: on a
+    //         tie the forward merge takes the right jump first, so backwards the left
+    //         one comes first)
     if (run) {
       uint32_t off = need;
       for (uint32_t node = S.N - 1u; node >= 1u; --node) {
         const uint32_t b = node - 1u;
-        const uint32_t mL = S.meta[((uint64_t)selL * B + b) * n + site - 1];
-        const uint32_t mR = S.meta[((uint64_t)selR * B + b) * n + site + 1];
-        const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
+        const PathRef L = path_ref(S, selL, b, site - 1), R = path_ref(S, selR, b, site + 1);
+        const uint32_t K = L.nj + R.nj + 1u;
         off -= K + 1u;
         double q0 = 1.0, q1 = 1.0;
         const uint32_t sub = S.subtree[node];
         if (sub == 1u) {
-          const uint32_t mM = S.meta[((uint64_t)selM * B + b) * n + site];
+          const uint32_t mM = S.meta[meta_idx(S, selM, b, site)];
           const uint32_t leaf_state = (mM >> 7) ^ (mM & 1u);
           q0 = leaf_state ? 0.0 : 1.0;
           q1 = leaf_state ? 1.0 : 0.0;
         } else {
           for (uint32_t ch = 1u; ch < sub; ch += S.subtree[node + ch]) {
-            const double *a = regA + ((size_t)(node + ch) * 64u + lane) * 2u;
-            q0 *= a[0];
+            const double *a = my + (size_t)(regA[(node + ch) * 64u + lane] & 0x7fffffffu) * 2u;
+            q0 *= a[0];   // p.front() of the child's branch
             q1 *= a[1];
           }
         }
-        double *recq = my + (size_t)(off + K) * 4u;
+        double *recq = my + (size_t)(off + K) * 2u;
         recq[0] = q0; recq[1] = q1;
+        regA[node * 64u + lane] = off;
         double n0 = q0, n1 = q1;
-#ifdef EPV_ABLATE_PRUNE
-        for (uint32_t kk = K; kk-- > 0u;) { double *rec = my + (size_t)(off + kk) * 4u; rec[0] = 0.5; rec[1] = 0.5; }
-        for (uint32_t kk = 0; kk-- > 0u;) {
-#else
+        uint32_t i = L.nj, j = R.nj;
+        uint32_t trip0 = (4u * L.init + R.init) ^ ((i & 1u) << 2) ^ (j & 1u);  // context of the LAST segment
+        double seg_end = s_blen[node];
+        double tl = i ? L.j[(uint64_t)(i - 1u) * n] : -EPV_INF;
+        double tr = j ? R.j[(uint64_t)(j - 1u) * n] : -EPV_INF;
         for (uint32_t kk = K; kk-- > 0u;) {
-#endif
-          double *rec = my + (size_t)(off + kk) * 4u;
-          const double len = rec[2];
-          const uint32_t trip0 = (uint32_t)epv_d2u(rec[3]);
+          const bool take_left = (kk > 0u) && (tl >= tr);
+          const double seg_start = (kk == 0u) ? 0.0 : (take_left ? tl : tr);
+          const double len = seg_end - seg_start;
           const double r0 = s_rates[trip0], r1 = s_rates[trip0 | 2u];
           // continuous_time_trans_prob_mat (ContinuousTimeMarkovModel.cpp:143-161)
           const double h = 1.0 / epv_exp(len * (r0 + r1));
@@ -348,15 +377,19 @@ __global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
           const double P10 = 1.0 - P11;
           const double a = P00 * n0 + P01 * n1;
           const double c = P10 * n0 + P11 * n1;
+          double *rec = my + (size_t)(off + kk) * 2u;
           rec[0] = a; rec[1] = c;
           n0 = a; n1 = c;
+          if (kk > 0u) {
+            if (take_left) { trip0 ^= 4u; --i; tl = i ? L.j[(uint64_t)(i - 1u) * n] : -EPV_INF; }
+            else { trip0 ^= 1u; --j; tr = j ? R.j[(uint64_t)(j - 1u) * n] : -EPV_INF; }
+            seg_end = seg_start;
+          }
         }
-        double *mine = regA + ((size_t)node * 64u + lane) * 2u;
-        mine[0] = n0; mine[1] = n1;  // p.front() of the branch above `node`
       }
     }
 
-    // ---- 3. downward sampling of the segment END STATES (:180-255) fused with
+    // ---- 2. downward sampling of the segment END STATES (:180-255) fused with
     //         proposal_prob of the current path (:272-339).  The jump times inside the
     //         segments do not influence any state or log-probability, so they are NOT
     //         drawn here: a branch whose every segment keeps its state and provably
@@ -367,32 +400,36 @@ __global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
     double log_prob = 0.0, orig_proposal = 0.0;
     unsigned long long dirty = 0ull;   // bit (node-1) & 63, flushed every 64 branches
     {
-      uint32_t off = 0;
-      const uint32_t root_state = run ? (uint32_t)(S.meta[((uint64_t)selM * B) * n + site] >> 7) : 0u;
+      const uint32_t root_state = run ? (uint32_t)(S.meta[meta_idx(S, selM, 0u, site)] >> 7) : 0u;
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t b = node - 1u;
         if (run) {
-          const uint32_t mL = S.meta[((uint64_t)selL * B + b) * n + site - 1];
-          const uint32_t mR = S.meta[((uint64_t)selR * B + b) * n + site + 1];
-          const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
+          const PathRef L = path_ref(S, selL, b, site - 1), R = path_ref(S, selR, b, site + 1);
+          const uint32_t K = L.nj + R.nj + 1u;
+          const uint32_t off = regA[node * 64u + lane];
           const uint32_t par = S.parent[node];
-          const uint32_t start_state =
-              (par == 0u) ? root_state : (uint32_t)epv_d2u(regA[((size_t)par * 64u + lane) * 2u]);
+          const uint32_t start_state = (par == 0u) ? root_state : (regA[par * 64u + lane] >> 31);
           const PathRef cur = path_ref(S, selM, b, site);
           uint32_t prev = start_state;
           bool clean = true;
           unsigned long long word = 0ull;
           uint64_t *states = S.prop_states + ((uint64_t)b * n + site) * S.W;
+          // forward merge of the neighbours' jumps (Segment.cpp:35-79)
+          uint32_t trip0 = 4u * L.init + R.init, i = 0, j = 0;
+          double seg_start = 0.0;
+          double tl = L.nj ? L.j[0] : EPV_INF, tr = R.nj ? R.j[0] : EPV_INF;
           // walk of the current path
           uint32_t cs_start = cur.init, cs_end = cur.init, sj = 0, ej = 0;
           double end_time = 0.0, lp = 0.0;
           double cur_next = cur.nj ? cur.j[0] : EPV_INF;
+          double pk0 = my[(size_t)off * 2u], pk1 = my[(size_t)off * 2u + 1u];
           for (uint32_t k = 0; k < K; ++k) {
-            const double *rec = my + (size_t)(off + k) * 4u;
-            const double pk0 = rec[0], pk1 = rec[1];
-            const double len = rec[2];
-            const uint32_t trip0 = (uint32_t)epv_d2u(rec[3]);
-            const double nxt0 = rec[4];  // p[k+1][0], or q[0] after the last segment
+            const bool last = (k + 1u == K);
+            const bool take_left = tl < tr;
+            const double seg_end = last ? s_blen[node] : (take_left ? tl : tr);
+            const double len = seg_end - seg_start;
+            const double nxt0 = my[(size_t)(off + k + 1u) * 2u];      // p[k+1][0], or q[0]
+            const double nxt1 = my[(size_t)(off + k + 1u) * 2u + 1u];
             const double r0 = s_rates[trip0], r1 = s_rates[trip0 | 2u];
             const double h = epv_exp(-len * (r0 + r1));
             const double denom = r0 + r1;
@@ -424,13 +461,18 @@ __global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
             cs_start = cs_end;
 #endif
             prev = sampled;
+            pk0 = nxt0; pk1 = nxt1;
+            if (!last) {
+              if (take_left) { trip0 ^= 4u; ++i; tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF; }
+              else { trip0 ^= 1u; ++j; tr = j < R.nj ? R.j[(uint64_t)j * n] : EPV_INF; }
+              seg_start = seg_end;
+            }
           }
           if (K & 63u) states[(K - 1u) >> 6] = word;
           // proposal so far: no jumps; epv_mh_jumps_kernel fills dirty branches in
-          S.meta[((uint64_t)(selM ^ 1u) * B + b) * n + site] = (uint8_t)(start_state << 7);
-          regA[((size_t)node * 64u + lane) * 2u] = epv_u2d((uint64_t)prev);  // proposal end state
+          S.meta[meta_idx(S, selM ^ 1u, b, site)] = (uint8_t)(start_state << 7);
+          regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children
           orig_proposal += lp;
-          off += K + 1u;
           if (!clean) dirty |= 1ull << (b & 63u);
         }
         // flush the dirty (site, branch) pairs of the last <= 64 branches: ONE atomic per
@@ -464,7 +506,6 @@ __global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
       pending = false;
     }
   }
-
 }
 
 // =========================================================================
@@ -477,7 +518,8 @@ __global__ __launch_bounds__(64, 2) void epv_mh_propose_kernel(
 //  numbers the oracle draws inside its single per-site function.
 // =========================================================================
 #define EPV_TJ 4u          /* jumps a search lane hands over through LDS */
-#define EPV_INLINE_TRIALS 4u /* trials a lane runs by itself before asking the wave for help */
+#define EPV_INLINE_TRIALS 8u /* trials a lane scans by itself before asking the wave for help */
+#define EPV_COOP_WINDOW 16u  /* consecutive trials one helper lane scans per round */
 
 __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
                                                            uint32_t seed_hi, uint32_t sweep,
@@ -485,14 +527,15 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   // per-wave cooperative-search area: task slots by rank and per-lane trial results
   __shared__ double c_len_[4][64], c_r0_[4][64], c_r1_[4][64], c_tj_[4][64 * EPV_TJ];
-  __shared__ uint32_t c_misc_[4][64], c_gsite_[4][64], c_tbase_[4][64], c_nk_[4][64], c_res_[4][64];
+  __shared__ uint32_t c_misc_[4][64], c_gsite_[4][64], c_tbase_[4][64], c_nk_[4][64], c_res_[4][64],
+      c_tw_[4][64];
   stage_constants(S, s_mem);
   const double *s_rates = s_mem, *s_blen = s_mem + 20;
   const uint32_t wave = threadIdx.x >> 6;
   const int lane = epv_lane();
   double *c_len = c_len_[wave], *c_r0 = c_r0_[wave], *c_r1 = c_r1_[wave], *c_tj = c_tj_[wave];
   uint32_t *c_misc = c_misc_[wave], *c_gsite = c_gsite_[wave], *c_tbase = c_tbase_[wave],
-           *c_nk = c_nk_[wave], *c_res = c_res_[wave];
+           *c_nk = c_nk_[wave], *c_res = c_res_[wave], *c_tw = c_tw_[wave];
   const unsigned long long n_tasks = counters[EPV_CNT_TASKS];
   const uint64_t n = S.n;
   const uint32_t B = S.B, C = S.C;
@@ -526,7 +569,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
       L = path_ref(S, selL, b, site - 1);
       R = path_ref(S, selR, b, site + 1);
       states = S.prop_states + ((uint64_t)b * n + site) * S.W;
-      meta = S.meta + ((uint64_t)selP * B + b) * n + site;
+      meta = S.meta + meta_idx(S, selP, b, site);
       dst = S.jumps + ((uint64_t)selP * B + b) * C * n + site;
       start_state = (uint32_t)(*meta >> 7);
       prev = start_state;
@@ -548,20 +591,10 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
         sampled = (uint32_t)(word >> (k & 63u)) & 1u;
         r0 = s_rates[trip0]; r1 = s_rates[trip0 | 2u];
         if (!ovf) {
-          const double b0 = nojump_bound(len * r0), b1 = nojump_bound(len * r1);
-          uint32_t njt;
-          // trial 1: first draw = second half of the segment's state block
-          int oc = run_trial(seed_lo, seed_hi, gsite, sweep, node, k, 1u,
-                             epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, 0u, 0u).d1, prev,
-                             sampled, len, r0, r1, b0, b1, C - cnt, dst + (uint64_t)cnt * n, n,
-                             0xffffffffu, time_passed, njt);
-          for (uint32_t t = 2u; oc == TRIAL_FAIL && t <= EPV_INLINE_TRIALS; ++t) {
-            const epv_block2 fb = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, t >> 1,
-                                                  EPV_FIRST_DRAW_BLOCK);
-            oc = run_trial(seed_lo, seed_hi, gsite, sweep, node, k, t, (t & 1u) ? fb.d1 : fb.d0, prev,
-                           sampled, len, r0, r1, b0, b1, C - cnt, dst + (uint64_t)cnt * n, n,
-                           0xffffffffu, time_passed, njt);
-          }
+          uint32_t njt, tw;
+          const int oc = scan_trials(seed_lo, seed_hi, gsite, sweep, node, k, 1u, EPV_INLINE_TRIALS, prev,
+                                     sampled, len, r0, r1, C - cnt, dst + (uint64_t)cnt * n, n,
+                                     0xffffffffu, time_passed, tw, njt);
           if (oc == TRIAL_OK) cnt += njt;
           else if (oc == TRIAL_OVERFLOW) ovf = true;
           else pend = true;
@@ -569,10 +602,10 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
       }
       // Wave-cooperative search for the first non-failing trial t > EPV_INLINE_TRIALS of
       // every still-pending lane.  The P pending tasks share the 64 lanes: the task of rank
-      // r gets the G = 2^floor(log2(64/P)) lanes [rG, rG+G), which evaluate G consecutive
-      // trials of that ONE segment (random-access RNG); the lowest non-failing trial wins
-      // and hands its jump times over through LDS; tasks that found none advance their
-      // window by G.  A leaf that forces a flip on a short branch needs ~1/P(a->b) trials
+      // r gets the G = 2^floor(log2(64/P)) lanes [rG, rG+G), each scanning a window of
+      // EPV_COOP_WINDOW consecutive trials of that ONE segment (random-access RNG); the lowest non-failing trial wins
+      // and hands its jump times over through LDS; tasks that found none advance by
+      // G * EPV_COOP_WINDOW trials.  A leaf that forces a flip on a short branch needs ~1/P(a->b) trials
       // (hundreds for the slowest context); this turns that serial tail into a few
       // full-width rounds.  Identical to the sequential "first non-failing t" whatever P, G.
       unsigned long long todo = __ballot(pend);
@@ -595,14 +628,12 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
         if (tj < P) {
           const uint32_t misc = c_misc[tj], nk = c_nk[tj];
           const double t_len = c_len[tj], t_r0 = c_r0[tj], t_r1 = c_r1[tj];
-          const uint32_t t = c_tbase[tj] + tr_, t_site = c_gsite[tj];
-          const epv_block2 fb = epv_keyed_block(seed_lo, seed_hi, t_site, sweep, nk >> 12, nk & 4095u,
-                                                t >> 1, EPV_FIRST_DRAW_BLOCK);
-          uint32_t njt;
-          oc = run_trial(seed_lo, seed_hi, t_site, sweep, nk >> 12, nk & 4095u, t,
-                         (t & 1u) ? fb.d1 : fb.d0, misc & 1u, (misc >> 1) & 1u, t_len, t_r0, t_r1,
-                         nojump_bound(t_len * t_r0), nojump_bound(t_len * t_r1), misc >> 8,
-                         c_tj + (size_t)lane * EPV_TJ, 1u, EPV_TJ, 0.0, njt);
+          const uint32_t t0 = c_tbase[tj] + tr_ * EPV_COOP_WINDOW, t_site = c_gsite[tj];
+          uint32_t njt, tw = 0u;
+          oc = scan_trials(seed_lo, seed_hi, t_site, sweep, nk >> 12, nk & 4095u, t0, EPV_COOP_WINDOW,
+                           misc & 1u, (misc >> 1) & 1u, t_len, t_r0, t_r1, misc >> 8,
+                           c_tj + (size_t)lane * EPV_TJ, 1u, EPV_TJ, 0.0, tw, njt);
+          c_tw[lane] = tw;
           c_res[lane] = (uint32_t)oc | (njt << 8);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -621,7 +652,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
                 for (uint32_t q = 0; q < njt; ++q)
                   d2[(uint64_t)q * n] = c_tj[(size_t)w * EPV_TJ + q] + time_passed;
               } else {  // rare: more jumps than the LDS hand-over holds -> replay the winner
-                const uint32_t tw = tbase + wi;
+                const uint32_t tw = c_tw[w];
                 const epv_block2 fb = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, tw >> 1,
                                                       EPV_FIRST_DRAW_BLOCK);
                 uint32_t nj2;
@@ -634,7 +665,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
             }
             pend = false;
           } else {
-            tbase += G;
+            tbase += G * EPV_COOP_WINDOW;
           }
         }
         todo = __ballot(pend);
@@ -812,7 +843,7 @@ __global__ __launch_bounds__(256) void epv_scale_kernel(EpvDev S, const double *
   const uint32_t buf = S.sel[site];
   for (uint32_t b = 0; b < S.B; ++b) {
     const uint64_t plane = (uint64_t)buf * S.B + b;
-    const uint32_t nj = S.meta[plane * S.n + site] & 127u;
+    const uint32_t nj = S.meta[meta_idx(S, buf, b, site)] & 127u;
     double *j = S.jumps + plane * S.C * S.n + site;
     const double sc = scale[b + 1];
     for (uint32_t k = 0; k < nj; ++k) j[(uint64_t)k * S.n] *= sc;
@@ -830,7 +861,7 @@ __global__ __launch_bounds__(256) void epv_scatter_kernel(EpvDev S, const uint8_
   const uint64_t b = e / S.n, site = e % S.n;
   const uint64_t o = offsets[e];
   const uint32_t cnt = (uint32_t)(offsets[e + 1] - o);
-  S.meta[b * S.n + site] = (uint8_t)((init[e] ? 0x80u : 0u) | cnt);  // buffer 0
+  S.meta[meta_idx(S, 0u, (uint32_t)b, site)] = (uint8_t)((init[e] ? 0x80u : 0u) | cnt);  // buffer 0
   double *j = S.jumps + b * S.C * S.n + site;
   for (uint32_t k = 0; k < cnt; ++k) j[(uint64_t)k * S.n] = jumps_csr[o + k];
   if (b == 0) { S.sel[site] = 0; S.tri[site] = 0.0; }
@@ -842,7 +873,7 @@ __global__ __launch_bounds__(256) void epv_count_kernel(EpvDev S, uint8_t *init_
   const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (uint64_t)S.B * S.n) return;
   const uint64_t b = e / S.n, site = e % S.n;
-  const uint8_t m = S.meta[((uint64_t)S.sel[site] * S.B + b) * S.n + site];
+  const uint8_t m = S.meta[meta_idx(S, S.sel[site], (uint32_t)b, site)];
   init_out[e] = m >> 7;
   counts[e] = m & 127u;
 }
@@ -853,7 +884,7 @@ __global__ __launch_bounds__(256) void epv_gather_kernel(EpvDev S, const uint64_
   if (e >= (uint64_t)S.B * S.n) return;
   const uint64_t b = e / S.n, site = e % S.n;
   const uint64_t plane = (uint64_t)S.sel[site] * S.B + b;
-  const uint32_t cnt = S.meta[plane * S.n + site] & 127u;
+  const uint32_t cnt = S.meta[meta_idx(S, S.sel[site], (uint32_t)b, site)] & 127u;
   const double *j = S.jumps + plane * S.C * S.n + site;
   const uint64_t o = offsets[e];
   for (uint32_t k = 0; k < cnt; ++k) jumps_csr[o + k] = j[(uint64_t)k * S.n];
@@ -877,11 +908,11 @@ __global__ void epv_pack_columns_kernel(EpvDev S, uint64_t first, uint64_t count
   for (uint32_t i = threadIdx.x; i < S.B * S.C; i += blockDim.x) {
     const uint32_t b = i / S.C, k = i % S.C;
     const uint64_t plane = (uint64_t)buf * S.B + b;
-    const uint32_t nj = S.meta[plane * S.n + site] & 127u;
+    const uint32_t nj = S.meta[meta_idx(S, buf, b, site)] & 127u;
     dj[i] = k < nj ? S.jumps[(plane * S.C + k) * S.n + site] : 0.0;
   }
   for (uint32_t b = threadIdx.x; b < S.B; b += blockDim.x)
-    col[b] = S.meta[((uint64_t)buf * S.B + b) * S.n + site];
+    col[b] = S.meta[meta_idx(S, buf, b, site)];
   if (threadIdx.x < 3) {
     const int64_t s = (int64_t)site + (int64_t)threadIdx.x - 1;
     dj[(uint64_t)S.B * S.C + threadIdx.x] = (s >= 0 && (uint64_t)s < S.n) ? S.tri[s] : 0.0;
@@ -902,7 +933,7 @@ __global__ void epv_unpack_columns_kernel(EpvDev S, uint64_t first, uint64_t cou
     if (k < nj) S.jumps[(((uint64_t)buf * S.B + b) * S.C + k) * S.n + site] = dj[i];
   }
   for (uint32_t b = threadIdx.x; b < S.B; b += blockDim.x)
-    S.meta[((uint64_t)buf * S.B + b) * S.n + site] = col[b];
+    S.meta[meta_idx(S, buf, b, site)] = col[b];
   if (threadIdx.x < 3) {
     const int64_t s = (int64_t)site + (int64_t)threadIdx.x - 1;
     if (s >= 0 && (uint64_t)s < S.n) S.tri[s] = dj[(uint64_t)S.B * S.C + threadIdx.x];
