@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,12 +37,14 @@ struct epv_ctx {
   uint32_t *d_parent = nullptr, *d_subtree = nullptr;
   double *d_blen = nullptr;
   unsigned long long *d_counters = nullptr;
+  unsigned long long *h_counters = nullptr;  // pinned staging for the sharded counters
   double *d_partial[2] = {nullptr, nullptr};  // tree-reduction ping-pong
   uint64_t partial_cap = 0;
   double *d_jd_acc = nullptr;  // [B*16] accumulated over batch sweeps
   double *d_scale = nullptr;
   // launch shape of the MH kernel
   uint32_t mh_threads = 64, pool_entries = 0;
+  uint32_t tasks_per_wave = 16;  // epv_mh_jumps_kernel: lanes of a wave that own a task
   double kbar = 0.0;  // mean jumps per (site, branch) of the uploaded paths
   size_t mh_lds = 0;
   // counters / timing
@@ -185,10 +188,12 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   {
     // one lane per dirty (site, branch) pair; the count is only known on the device, so
     // launch a grid that covers the typical case and grid-stride over the rest
-    const uint64_t max_tasks = threads * c->S.B;
-    const uint64_t jb = std::min<uint64_t>((max_tasks + 255u) / 256u, 2048u);
-    hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb), dim3(256), const_lds_bytes(c->S.N),
-                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, c->d_counters);
+    const uint64_t max_tasks = blocks / EPV_SHARDS * 64u * c->S.B + 64u * c->S.B;  // per shard
+    const uint32_t tpw = c->tasks_per_wave;
+    // a block (4 waves) takes 4*tpw tasks per pass; size the grid for ~1/4 of the worst case
+    const uint64_t jb = std::min<uint64_t>((max_tasks / 4u + 4u * tpw - 1u) / (4u * tpw) + 1u, 256u);
+    hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
+                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, c->d_counters);
   }
   hipLaunchKernelGGL(epv_mh_accept_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256),
                      const_lds_bytes(c->S.N), c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
@@ -212,9 +217,14 @@ int drain_timing(epv_ctx *c) {
 }
 
 int read_counters(epv_ctx *c, unsigned long long out[EPV_CNT_N]) {
-  HIP_TRY(c, hipMemcpyAsync(out, c->d_counters, sizeof(unsigned long long) * EPV_CNT_N,
+  unsigned long long *raw = c->h_counters;
+  HIP_TRY(c, hipMemcpyAsync(raw, c->d_counters, sizeof(unsigned long long) * EPV_CNT_WORDS,
                             hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t k = 0; k < EPV_CNT_N; ++k) {
+    out[k] = 0;
+    for (uint32_t s = 0; s < EPV_SHARDS; ++s) out[k] += raw[EPV_CNT_IDX(k, s)];
+  }
   return drain_timing(c);
 }
 
@@ -234,10 +244,15 @@ EPV_API epv_ctx *epv_create(int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return nullptr;
   epv_ctx *c = new epv_ctx();
   c->device = device_id;
+  if (const char *e = std::getenv("EPV_TASKS_PER_WAVE")) {  // tuning knob
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 64) c->tasks_per_wave = (uint32_t)v;
+  }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc(&c->d_model, sizeof(EpvModelConst)) != hipSuccess ||
-      hipMalloc(&c->d_counters, sizeof(unsigned long long) * EPV_CNT_N) != hipSuccess ||
-      hipMemset(c->d_counters, 0, sizeof(unsigned long long) * EPV_CNT_N) != hipSuccess) {
+      hipMalloc(&c->d_counters, sizeof(unsigned long long) * EPV_CNT_WORDS) != hipSuccess ||
+      hipHostMalloc(&c->h_counters, sizeof(unsigned long long) * EPV_CNT_WORDS) != hipSuccess ||
+      hipMemset(c->d_counters, 0, sizeof(unsigned long long) * EPV_CNT_WORDS) != hipSuccess) {
     delete c;
     return nullptr;
   }
@@ -254,6 +269,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
   dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale);
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -345,7 +361,9 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   HIP_TRY(c, hipMalloc(&c->S.prop_flag, n_sites));
   c->S.W = (2u * capacity + 1u + 63u) / 64u;
   HIP_TRY(c, hipMalloc(&c->S.prop_states, E * c->S.W * sizeof(uint64_t)));
-  HIP_TRY(c, hipMalloc(&c->S.tasks, ((n_sites + 2u) / 3u + 1u) * B * sizeof(unsigned long long)));
+  // one task region per counter shard, sized for the worst case of the blocks that use it
+  c->S.task_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u * B;
+  HIP_TRY(c, hipMalloc(&c->S.tasks, c->S.task_cap * EPV_SHARDS * sizeof(unsigned long long)));
   HIP_TRY(c, hipMemsetAsync(c->S.meta, 0, 2u * E, c->stream));
   // staging of the CSR form
   uint8_t *d_init = nullptr;

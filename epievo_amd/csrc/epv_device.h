@@ -39,7 +39,9 @@ struct EpvDev {
   double *prop_llr;   // [n] q(old)-q(new) of the pending proposal (propose -> accept kernel)
   uint8_t *prop_flag; // [n] 1 = the pending proposal overflowed the capacity
   uint64_t *prop_states;  // [B][n][W] sampled segment end states of the pending proposal, 1 bit each
-  unsigned long long *tasks;  // dirty (branch<<40 | site) pairs of the current colour phase
+  unsigned long long *tasks;  // dirty (branch<<40 | site) pairs of the current colour phase,
+                              // EPV_SHARDS regions of task_cap entries each
+  uint64_t task_cap;
   uint32_t W;        // 64-bit words per (site, branch) in prop_states = ceil((2C+1)/64)
   const EpvModelConst *model;  // device copy
   const uint32_t *parent;      // [N]
@@ -49,5 +51,12 @@ struct EpvDev {
 
 // counters[] slots
 enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_N = 4 };
+// Every counter is sharded 64 ways with a 128-byte stride (one device-scope atomic word
+// saturates near 90 ops/us; 5000 waves hitting ONE word would serialise for ~60 us).
+// A block uses shard (blockIdx.x & 63); the host sums the shards.
+#define EPV_SHARDS 64u
+#define EPV_SHARD_STRIDE 16u /* u64 words = 128 B */
+#define EPV_CNT_WORDS (EPV_CNT_N * EPV_SHARDS * EPV_SHARD_STRIDE)
+#define EPV_CNT_IDX(kind, shard) (((kind) * EPV_SHARDS + (shard)) * EPV_SHARD_STRIDE)
 
 #endif

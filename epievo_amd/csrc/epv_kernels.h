@@ -105,8 +105,30 @@ __device__ __forceinline__ void acc_add(Acc8 &A, int ctx, double dt, bool mid) {
 
 // Path.cpp:206-301 as one 3-way merge with +inf sentinels; tie rules: left only if
 // strictly below min(mid,right), else mid only if strictly below right, else right.
+// Same accumulator kept in LDS (one column per thread, element c at [c * stride]): a
+// runtime-indexed read-modify-write costs ~6 instructions instead of the ~40 of the
+// register select chain; used where a kernel is bound by instruction issue.
+struct AccLds {
+  double *d;
+  uint32_t *j;
+  uint32_t stride;
+};
+__device__ __forceinline__ void acc_clear(AccLds &A) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { A.d[c * A.stride] = 0.0; A.j[c * A.stride] = 0u; }
+}
+__device__ __forceinline__ void acc_add(AccLds &A, int ctx, double dt, bool mid) {
+  A.d[ctx * A.stride] += dt;
+  if (mid) A.j[ctx * A.stride] += 1u;
+}
+__device__ __forceinline__ double acc_d(const Acc8 &A, int c) { return A.d[c]; }
+__device__ __forceinline__ uint32_t acc_j(const Acc8 &A, int c) { return A.j[c]; }
+__device__ __forceinline__ double acc_d(const AccLds &A, int c) { return A.d[c * A.stride]; }
+__device__ __forceinline__ uint32_t acc_j(const AccLds &A, int c) { return A.j[c * A.stride]; }
+
+template <class ACC>
 __device__ __forceinline__ void merge3(const PathRef &L, const PathRef &M, const PathRef &R,
-                                       uint64_t n, double tot_time, Acc8 &A) {
+                                       uint64_t n, double tot_time, ACC &A) {
   int ctx = (int)(4u * L.init + 2u * M.init + R.init);
   double prev = 0.0;
   uint32_t i = 0, j = 0, k = 0;
@@ -134,11 +156,11 @@ __device__ __forceinline__ void merge3(const PathRef &L, const PathRef &M, const
 // path_log_likelihood (SingleSiteSampler.cpp:374-391): un-logged root prior (reference
 // quirk) + sum_c J_c log(rate_c) - D_c rate_c over all branches of one triple.
 // (bl,sl),(bm,sm),(br,sr) = (buffer, site) of the left / middle / right column.
+template <class ACC>
 __device__ __forceinline__ double triple_llh(const EpvDev &S, const double *s_model,
                                              const double *s_blen, uint32_t bl, uint64_t sl,
                                              uint32_t bm, uint64_t sm, uint32_t br,
-                                             uint64_t sr) {
-  Acc8 A;
+                                             uint64_t sr, ACC &A) {
   acc_clear(A);
   uint32_t rl = 0, rm = 0, rr = 0;
   for (uint32_t b = 0; b < S.B; ++b) {
@@ -151,7 +173,7 @@ __device__ __forceinline__ double triple_llh(const EpvDev &S, const double *s_mo
   double llh = T[2 * rl + rm] * T[2 * rm + rr];
   double s = 0.0;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) s += (double)A.j[c] * lrates[c] - A.d[c] * rates[c];
+  for (int c = 0; c < 8; ++c) s += (double)acc_j(A, c) * lrates[c] - acc_d(A, c) * rates[c];
   llh += s;
   return llh;
 }
@@ -483,10 +505,12 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
           const uint32_t total = __shfl(incl_t, 63);
           if (total) {
             unsigned long long base = 0ull;
-            if (lane == 0) base = atomicAdd(&counters[EPV_CNT_TASKS], (unsigned long long)total);
+            const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+            if (lane == 0)
+              base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)], (unsigned long long)total);
             base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0) << 32) |
                    (unsigned long long)__shfl((uint32_t)base, 0);
-            unsigned long long slot = base + (incl_t - mine);
+            unsigned long long slot = (unsigned long long)shard * S.task_cap + base + (incl_t - mine);
             unsigned long long d = dirty;
             while (d) {
               const uint32_t bit = (uint32_t)(__ffsll((long long)d) - 1);
@@ -523,6 +547,7 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
 
 __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
                                                            uint32_t seed_hi, uint32_t sweep,
+                                                           uint32_t tasks_per_wave,
                                                            unsigned long long *counters) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   // per-wave cooperative-search area: task slots by rank and per-lane trial results
@@ -536,16 +561,19 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
   double *c_len = c_len_[wave], *c_r0 = c_r0_[wave], *c_r1 = c_r1_[wave], *c_tj = c_tj_[wave];
   uint32_t *c_misc = c_misc_[wave], *c_gsite = c_gsite_[wave], *c_tbase = c_tbase_[wave],
            *c_nk = c_nk_[wave], *c_res = c_res_[wave], *c_tw = c_tw_[wave];
-  const unsigned long long n_tasks = counters[EPV_CNT_TASKS];
+  const uint32_t shard = blockIdx.y;   // one task-list region per counter shard
+  const unsigned long long n_tasks = counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)];
+  const unsigned long long *tasks = S.tasks + (unsigned long long)shard * S.task_cap;
   const uint64_t n = S.n;
   const uint32_t B = S.B, C = S.C;
-  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  // every wave makes the same number of passes so that the cooperative parts stay
-  // wave-uniform; lanes without a task idle as helpers
-  for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < n_tasks;
-       base += stride) {
-    const unsigned long long ti = base + threadIdx.x;
-    bool active = ti < n_tasks;
+  // Only the first `tasks_per_wave` lanes of a wave own a task; the others are pure
+  // helpers for the cooperative search.  Fewer tasks per wave = more waves in flight and a
+  // shorter critical path for the rare very hard task (1/P(a->b) in the hundreds).
+  const unsigned long long stride = (unsigned long long)gridDim.x * 4u * tasks_per_wave;
+  for (unsigned long long base = ((unsigned long long)blockIdx.x * 4u + wave) * tasks_per_wave;
+       base < n_tasks; base += stride) {
+    const unsigned long long ti = base + (unsigned)lane;
+    bool active = (uint32_t)lane < tasks_per_wave && ti < n_tasks;
     uint64_t site = 0;
     uint32_t b = 0, node = 1, gsite = 0, start_state = 0, prev = 0, cnt = 0, k = 0;
     uint32_t trip0 = 0, i = 0, j = 0;
@@ -560,7 +588,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
     unsigned long long word = 0ull;
     bool ovf = false;
     if (active) {
-      const unsigned long long task = S.tasks[ti];
+      const unsigned long long task = tasks[ti];
       site = task & 0xffffffffffull;
       b = (uint32_t)(task >> 40);
       node = b + 1u;
@@ -704,9 +732,13 @@ __global__ __launch_bounds__(256) void epv_mh_accept_kernel(
     uint64_t first, uint64_t last, uint64_t own_first, uint64_t own_last,
     unsigned long long *counters) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  __shared__ double s_accd[8 * 256];
+  __shared__ uint32_t s_accj[8 * 256];
   stage_constants(S, s_mem);
   const double *s_const = s_mem, *s_blen = s_mem + 20;
   const int lane = epv_lane();
+  AccLds A;
+  A.d = s_accd + threadIdx.x; A.j = s_accj + threadIdx.x; A.stride = 256u;
   const uint64_t gfirst = S.g0 + first;
   const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -722,13 +754,21 @@ __global__ __launch_bounds__(256) void epv_mh_accept_kernel(
     double llr = S.prop_llr[site];
     const double llh_l_orig = llh_l, llh_r_orig = llh_r;
     if (!ovf) {
+      // the three triples centred at site-1, site, site+1 with the proposal standing in
+      // for this site's column (one loop, so merge3 is instantiated once)
       const uint32_t selP = selM ^ 1u;
       const uint64_t g = S.g0 + site;
-      if (g > 1u)
-        llh_l = triple_llh(S, s_const, s_blen, S.sel[site - 2], site - 2, selL, site - 1, selP, site);
-      llh_m = triple_llh(S, s_const, s_blen, selL, site - 1, selP, site, selR, site + 1);
-      if (g < S.n_global - 2u)
-        llh_r = triple_llh(S, s_const, s_blen, selP, site, selR, site + 1, S.sel[site + 2], site + 2);
+      const uint32_t selLL = (g > 1u) ? S.sel[site - 2] : 0u;
+      const uint32_t selRR = (g < S.n_global - 2u) ? S.sel[site + 2] : 0u;
+      for (int w = 0; w < 3; ++w) {
+        if ((w == 0 && !(g > 1u)) || (w == 2 && !(g < S.n_global - 2u))) continue;
+        const uint64_t c = site - 1u + (uint64_t)w;
+        const uint32_t bl = (w == 0) ? selLL : (w == 1) ? selL : selP;
+        const uint32_t bm = (w == 0) ? selL : (w == 1) ? selP : selR;
+        const uint32_t br = (w == 0) ? selP : (w == 1) ? selR : selRR;
+        const double v = triple_llh(S, s_const, s_blen, bl, c - 1u, bm, c, br, c + 1u, A);
+        if (w == 0) llh_l = v; else if (w == 1) llh_m = v; else llh_r = v;
+      }
     }
     llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
     const double u = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, 0u, 0u, 0u, 0u).d0;
@@ -745,14 +785,15 @@ __global__ __launch_bounds__(256) void epv_mh_accept_kernel(
   }
   const unsigned long long am = __ballot(accepted), om = __ballot(overflowed);
   if (lane == 0) {
-    if (am) atomicAdd(&counters[EPV_CNT_ACCEPT], (unsigned long long)__popcll(am));
-    if (om) atomicAdd(&counters[EPV_CNT_OVERFLOW], (unsigned long long)__popcll(om));
+    const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+    if (am) atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_ACCEPT, shard)], (unsigned long long)__popcll(am));
+    if (om) atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_OVERFLOW, shard)], (unsigned long long)__popcll(om));
   }
-  // the task list of this phase has been consumed (stream order): fold its length into
-  // the running total and clear it for the next propose kernel
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    counters[EPV_CNT_COOP] += counters[EPV_CNT_TASKS];
-    counters[EPV_CNT_TASKS] = 0ull;
+  // the task lists of this phase have been consumed (stream order): fold their lengths
+  // into the running total and clear them for the next propose kernel
+  if (blockIdx.x == 0 && threadIdx.x < EPV_SHARDS) {
+    counters[EPV_CNT_IDX(EPV_CNT_COOP, threadIdx.x)] += counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)];
+    counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)] = 0ull;
   }
 }
 
@@ -765,9 +806,11 @@ __global__ __launch_bounds__(256) void epv_reset_kernel(EpvDev S) {
   const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (site >= S.n) return;
   double v = 0.0;
-  if (site >= 1 && site + 1 < S.n)
+  if (site >= 1 && site + 1 < S.n) {
+    Acc8 A;
     v = triple_llh(S, s_mem, s_mem + 20, S.sel[site - 1], site - 1, S.sel[site], site,
-                   S.sel[site + 1], site + 1);
+                   S.sel[site + 1], site + 1, A);
+  }
   S.tri[site] = v;
 }
 
