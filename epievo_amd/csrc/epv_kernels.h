@@ -255,11 +255,22 @@ __device__ __forceinline__ int scan_trials(uint32_t seed_lo, uint32_t seed_hi, u
   uint32_t t = t0;
   const uint32_t t_end = t0 + W;
   nj_out = 0;
+  epv_block2 fb;             // first-draw block of the trial pair (2m, 2m+1), reused for 2m+1
+  fb.d0 = fb.d1 = 0.0;
+  uint32_t fb_pair = 0xffffffffu;
   for (;;) {
     double u = 0.0;
     bool cand = false;
     for (; t < t_end; ++t) {
-      u = first_draw(seed_lo, seed_hi, gsite, sweep, node, k, t);
+      if (t == 1u) {
+        u = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, 0u, 0u).d1;
+      } else {
+        if ((t >> 1) != fb_pair) {
+          fb_pair = t >> 1;
+          fb = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, fb_pair, EPV_FIRST_DRAW_BLOCK);
+        }
+        u = (t & 1u) ? fb.d1 : fb.d0;
+      }
       if (1.0 - u < bound) {              // provably no jump in this trial
         if (a0 == end) { t_out = t; nj_out = 0; return TRIAL_OK; }
       } else {
@@ -542,8 +553,12 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
 //  numbers the oracle draws inside its single per-site function.
 // =========================================================================
 #define EPV_TJ 4u          /* jumps a search lane hands over through LDS */
+#ifndef EPV_INLINE_TRIALS
 #define EPV_INLINE_TRIALS 8u /* trials a lane scans by itself before asking the wave for help */
+#endif
+#ifndef EPV_COOP_WINDOW
 #define EPV_COOP_WINDOW 16u  /* consecutive trials one helper lane scans per round */
+#endif
 
 __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
                                                            uint32_t seed_hi, uint32_t sweep,
@@ -820,22 +835,38 @@ __global__ __launch_bounds__(256) void epv_reset_kernel(EpvDev S) {
 //  local site index (lane butterfly -> 4 waves through LDS -> block partials ->
 //  epv_tree_reduce_kernel levels).  partial layout: [block][b][16] (J then D).
 // =========================================================================
-__device__ __forceinline__ double block_tree_sum_256(double v, double *s_red) {
+
+// Sum 16 per-lane values over the wave in the canonical balanced-tree order with a
+// transpose-reduce: at stage s (xor 1,2,4,8) a lane keeps half of its values and
+// trades the other half with its partner, so the 16 butterflies of 6 stages each (96
+// shuffles + 96 adds) become 8+4+2+1 exchanges plus two full-width stages.  Every
+// individual sum still pairs lanes (i, i^1), then (i, i^2), ... exactly as the plain
+// xor butterfly does, so the result is bit-identical to it.  On return lane l holds
+// the wave total of value index idx(l) = 8*bit0 + 4*bit1 + 2*bit2 + bit3 of l.
+__device__ __forceinline__ double wave_tree_sum16(const double v[16], int lane, int &idx) {
+  double w[8], x[4], y[2], z;
+  const bool h0 = lane & 1, h1 = lane & 2, h2 = lane & 4, h3 = lane & 8;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) v = v + shfl_xor_f64(v, d);
-  const uint32_t wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (epv_lane() == 0) s_red[wave] = v;
-  __syncthreads();
-  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  for (int i = 0; i < 8; ++i) w[i] = (h0 ? v[i + 8] : v[i]) + shfl_xor_f64(h0 ? v[i] : v[i + 8], 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = (h1 ? w[i + 4] : w[i]) + shfl_xor_f64(h1 ? w[i] : w[i + 4], 2);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) y[i] = (h2 ? x[i + 2] : x[i]) + shfl_xor_f64(h2 ? x[i] : x[i + 2], 4);
+  z = (h3 ? y[1] : y[0]) + shfl_xor_f64(h3 ? y[0] : y[1], 8);
+  z = z + shfl_xor_f64(z, 16);
+  z = z + shfl_xor_f64(z, 32);
+  idx = (h0 ? 8 : 0) + (h1 ? 4 : 0) + (h2 ? 2 : 0) + (h3 ? 1 : 0);
+  return z;
 }
 
 __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t first,
                                                            uint64_t last, double *partial) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
-  __shared__ double s_red[4];
+  __shared__ double s_part[2][4][16];
   stage_constants(S, s_mem);
   const double *s_blen = s_mem + 20;
+  const int lane = epv_lane();
+  const uint32_t wave = threadIdx.x >> 6;
   const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool on = site >= first && site <= last && site >= 1 && site + 1 < S.n;
   uint32_t sl = 0, sm = 0, sr = 0;
@@ -848,26 +879,42 @@ __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t fi
                     R = path_ref(S, sr, b, site + 1);
       merge3(L, M, R, S.n, s_blen[b + 1], A);
     }
-    double *out = partial + ((uint64_t)blockIdx.x * S.B + b) * 16u;
+    double v[16];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const double js = block_tree_sum_256((double)A.j[c], s_red);
-      const double ds = block_tree_sum_256(A.d[c], s_red);
-      if (threadIdx.x == 0) { out[c] = js; out[8 + c] = ds; }
+    for (int c = 0; c < 8; ++c) { v[c] = (double)A.j[c]; v[8 + c] = A.d[c]; }
+    int idx;
+    const double tot = wave_tree_sum16(v, lane, idx);
+    if (lane < 16) s_part[b & 1u][wave][idx] = tot;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      const double(*p)[16] = s_part[b & 1u];
+      partial[((uint64_t)blockIdx.x * S.B + b) * 16u + threadIdx.x] =
+          (p[0][threadIdx.x] + p[1][threadIdx.x]) + (p[2][threadIdx.x] + p[3][threadIdx.x]);
     }
   }
 }
 
-// one level of the tree: in[m][V] -> out[ceil(m/256)][V], each block sums 256
-// consecutive (aligned) entries of every value column in balanced order
+// one level of the tree: in[m][V] -> out[ceil(m/256)][V] (V a multiple of 16), each block
+// sums 256 consecutive (aligned) entries of every value column in balanced order
 __global__ __launch_bounds__(256) void epv_tree_reduce_kernel(const double *in, uint64_t m,
                                                               uint32_t V, double *out) {
-  __shared__ double s_red[4];
-  const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  for (uint32_t v = 0; v < V; ++v) {
-    const double x = idx < m ? in[idx * V + v] : 0.0;
-    const double s = block_tree_sum_256(x, s_red);
-    if (threadIdx.x == 0) out[(uint64_t)blockIdx.x * V + v] = s;
+  __shared__ double s_part[2][4][16];
+  const int lane = epv_lane();
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint64_t idx_in = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  for (uint32_t g = 0; g < V / 16u; ++g) {
+    double v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = idx_in < m ? in[idx_in * V + g * 16u + c] : 0.0;
+    int idx;
+    const double tot = wave_tree_sum16(v, lane, idx);
+    if (lane < 16) s_part[g & 1u][wave][idx] = tot;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      const double(*p)[16] = s_part[g & 1u];
+      out[(uint64_t)blockIdx.x * V + g * 16u + threadIdx.x] =
+          (p[0][threadIdx.x] + p[1][threadIdx.x]) + (p[2][threadIdx.x] + p[3][threadIdx.x]);
+    }
   }
 }
 
