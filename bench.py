@@ -183,7 +183,7 @@ def main():
                        else "%s, n=%d per GPU" % (args.config, n_local),
                        "sites_per_gpu": n_local, "branches": B, "burn_in": BURN_IN, "batch": BATCH,
                        "mean_jumps_per_path": kbar, "sharding": "contiguous site shards, %d-column redundant halos refreshed once per step, %d shard(s)" % (ss.halo, world)},
-            "roofline": {"bound": "hbm", "kernel": "epv_mh_propose_kernel + epv_mh_accept_kernel (one colour phase = one timed launch pair)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "epv_mh_propose_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel (one colour phase = one timed launch triple)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_resample": bytes_per,
                          "resamples_per_launch": per_launch_units, "avg_launch_ms": avg_ms,

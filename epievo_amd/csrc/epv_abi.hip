@@ -167,6 +167,8 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   owned_range(c, &own_lo, &own_hi);
   const uint64_t span = last - first + 1u;
   const uint64_t threads = (span + 2u) / 3u;
+  // first local site of this colour (the kernels derive the same value)
+  const uint64_t s0 = first + (((uint32_t)colour + 3u - (uint32_t)((c->S.g0 + first) % 3u)) % 3u);
   const uint64_t blocks = (threads + c->mh_threads - 1u) / c->mh_threads;
   if (blocks == 0) return EPV_OK;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -193,7 +195,7 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     // a block (4 waves) takes 4*tpw tasks per pass; size the grid for ~1/4 of the worst case
     const uint64_t jb = std::min<uint64_t>((max_tasks / 4u + 4u * tpw - 1u) / (4u * tpw) + 1u, 256u);
     hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
-                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, c->d_counters);
+                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, c->d_counters);
   }
   hipLaunchKernelGGL(epv_mh_accept_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256),
                      const_lds_bytes(c->S.N), c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
@@ -357,10 +359,11 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   HIP_TRY(c, hipMalloc(&c->S.jumps, 2u * E * capacity * sizeof(double)));
   HIP_TRY(c, hipMalloc(&c->S.sel, n_sites));
   HIP_TRY(c, hipMalloc(&c->S.tri, n_sites * sizeof(double)));
-  HIP_TRY(c, hipMalloc(&c->S.prop_llr, n_sites * sizeof(double)));
-  HIP_TRY(c, hipMalloc(&c->S.prop_flag, n_sites));
+  c->S.phase_cap = (n_sites + 2u) / 3u + 1u;
+  HIP_TRY(c, hipMalloc(&c->S.prop_llr, c->S.phase_cap * sizeof(double)));
+  HIP_TRY(c, hipMalloc(&c->S.prop_flag, c->S.phase_cap));
   c->S.W = (2u * capacity + 1u + 63u) / 64u;
-  HIP_TRY(c, hipMalloc(&c->S.prop_states, E * c->S.W * sizeof(uint64_t)));
+  HIP_TRY(c, hipMalloc(&c->S.prop_states, B * c->S.phase_cap * c->S.W * sizeof(uint64_t)));
   // one task region per counter shard, sized for the worst case of the blocks that use it
   c->S.task_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u * B;
   HIP_TRY(c, hipMalloc(&c->S.tasks, c->S.task_cap * EPV_SHARDS * sizeof(unsigned long long)));

@@ -36,12 +36,14 @@ struct EpvDev {
   double *jumps;
   uint8_t *sel;
   double *tri;
-  double *prop_llr;   // [n] q(old)-q(new) of the pending proposal (propose -> accept kernel)
-  uint8_t *prop_flag; // [n] 1 = the pending proposal overflowed the capacity
-  uint64_t *prop_states;  // [B][n][W] sampled segment end states of the pending proposal, 1 bit each
+  double *prop_llr;   // [phase_cap] q(old)-q(new) of the pending proposal (propose -> accept kernel)
+  uint8_t *prop_flag; // [phase_cap] 1 = the pending proposal overflowed the capacity
+  uint64_t *prop_states;  // [B][phase_cap][W] sampled segment end states of the pending proposal, 1 bit each
   unsigned long long *tasks;  // dirty (branch<<40 | site) pairs of the current colour phase,
                               // EPV_SHARDS regions of task_cap entries each
   uint64_t task_cap;
+  uint64_t phase_cap;  // max sites of one colour phase; the hand-over arrays are indexed by
+                       // the phase-local thread id (site = s0 + 3*tid) so they are written densely
   uint32_t W;        // 64-bit words per (site, branch) in prop_states = ceil((2C+1)/64)
   const EpvModelConst *model;  // device copy
   const uint32_t *parent;      // [N]

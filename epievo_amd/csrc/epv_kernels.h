@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
           uint32_t prev = start_state;
           bool clean = true;
           unsigned long long word = 0ull;
-          uint64_t *states = S.prop_states + ((uint64_t)b * n + site) * S.W;
+          uint64_t *states = S.prop_states + ((uint64_t)b * S.phase_cap + tid) * S.W;
           // forward merge of the neighbours' jumps (Segment.cpp:35-79)
           uint32_t trip0 = 4u * L.init + R.init, i = 0, j = 0;
           double seg_start = 0.0;
@@ -536,8 +536,8 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
 
     // ---- hand-over to epv_mh_accept_kernel: q(old) - q(new) and the overflow flag
     if (run) {
-      S.prop_llr[site] = orig_proposal - log_prob;
-      S.prop_flag[site] = 0u;
+      S.prop_llr[tid] = orig_proposal - log_prob;
+      S.prop_flag[tid] = 0u;
       pending = false;
     }
   }
@@ -557,12 +557,12 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
 #define EPV_INLINE_TRIALS 8u /* trials a lane scans by itself before asking the wave for help */
 #endif
 #ifndef EPV_COOP_WINDOW
-#define EPV_COOP_WINDOW 16u  /* consecutive trials one helper lane scans per round */
+#define EPV_COOP_WINDOW 4u   /* consecutive trials one helper lane scans per round */
 #endif
 
 __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
                                                            uint32_t seed_hi, uint32_t sweep,
-                                                           uint32_t tasks_per_wave,
+                                                           uint32_t tasks_per_wave, uint64_t s0,
                                                            unsigned long long *counters) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   // per-wave cooperative-search area: task slots by rank and per-lane trial results
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
        base < n_tasks; base += stride) {
     const unsigned long long ti = base + (unsigned)lane;
     bool active = (uint32_t)lane < tasks_per_wave && ti < n_tasks;
-    uint64_t site = 0;
+    uint64_t site = 0, ptid = 0;
     uint32_t b = 0, node = 1, gsite = 0, start_state = 0, prev = 0, cnt = 0, k = 0;
     uint32_t trip0 = 0, i = 0, j = 0;
     PathRef L, R;
@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
       const uint32_t selL = S.sel[site - 1], selP = S.sel[site] ^ 1u, selR = S.sel[site + 1];
       L = path_ref(S, selL, b, site - 1);
       R = path_ref(S, selR, b, site + 1);
-      states = S.prop_states + ((uint64_t)b * n + site) * S.W;
+      ptid = (site - s0) / 3u;
+      states = S.prop_states + ((uint64_t)b * S.phase_cap + ptid) * S.W;
       meta = S.meta + meta_idx(S, selP, b, site);
       dst = S.jumps + ((uint64_t)selP * B + b) * C * n + site;
       start_state = (uint32_t)(*meta >> 7);
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
         if (last) {
           if (ovf) {
             cnt = (start_state ^ prev) & 1u;  // keep the end-state parity; the proposal is rejected
-            S.prop_flag[site] = 1u;
+            S.prop_flag[ptid] = 1u;
           }
           *meta = (uint8_t)((start_state << 7) | cnt);
           active = false;
@@ -762,11 +763,11 @@ __global__ __launch_bounds__(256) void epv_mh_accept_kernel(
   if (site <= last) {
     const uint32_t selL = S.sel[site - 1], selM = S.sel[site], selR = S.sel[site + 1];
     const uint32_t gsite = (uint32_t)(S.g0 + site);
-    const bool ovf = S.prop_flag[site] != 0;
+    const bool ovf = S.prop_flag[tid] != 0;
     double llh_l = S.tri[site - 1];
     double llh_m = S.tri[site];
     double llh_r = S.tri[site + 1];
-    double llr = S.prop_llr[site];
+    double llr = S.prop_llr[tid];
     const double llh_l_orig = llh_l, llh_r_orig = llh_r;
     if (!ovf) {
       // the three triples centred at site-1, site, site+1 with the proposal standing in
