@@ -394,6 +394,49 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   return plan_mh(c);
 }
 
+static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base);
+
+EPV_API int epv_init_paths_indep(epv_ctx *c, uint64_t n_sites, const uint8_t *root_states,
+                                 const uint8_t *leaf_states, uint64_t seed, uint32_t capacity) {
+  if (!c) return EPV_ERR_ARG;
+  if (!c->have_tree || !c->have_model)
+    return fail(c, EPV_ERR_STATE, "epv_set_tree and epv_set_model must come before epv_init_paths_indep");
+  if (c->S.N != 2) return fail(c, EPV_ERR_ARG, "epv_init_paths_indep needs the two-node (single branch) tree");
+  if (n_sites < 3 || !root_states || !leaf_states) return fail(c, EPV_ERR_ARG, "bad states");
+  // device paths start as (init = root, no jumps)
+  std::vector<uint64_t> off(n_sites + 1, 0);
+  double dummy = 0.0;
+  int rc = epv_upload_paths(c, n_sites, root_states, off.data(), &dummy, capacity ? capacity : 32u, 0);
+  if (rc) return rc;
+  uint8_t *d_leaf = nullptr;
+  HIP_TRY(c, hipMalloc(&d_leaf, n_sites));
+  HIP_TRY(c, hipMemcpyAsync(d_leaf, leaf_states, n_sites, hipMemcpyHostToDevice, c->stream));
+  const uint64_t first = 1, last = n_sites - 2;
+  const uint64_t threads = (last - first + 1u + 2u) / 3u;
+  const unsigned blocks = (unsigned)((threads + 255u) / 256u);
+  for (uint32_t colour = 0; colour < 3; ++colour) {
+    const uint64_t s0 = first + ((colour + 3u - (uint32_t)((c->S.g0 + first) % 3u)) % 3u);
+    // 64-lane blocks like epv_mh_propose_kernel: the per-shard task regions are sized for them
+    hipLaunchKernelGGL(epv_init_tasks_kernel, dim3((unsigned)((threads + 63u) / 64u)), dim3(64), 0, c->stream,
+                       c->S, colour, first, last, d_leaf, c->d_counters);
+    const uint64_t per_shard = threads / EPV_SHARDS + 256u;
+    const uint64_t jb = std::min<uint64_t>((per_shard + 4u * c->tasks_per_wave - 1u) / (4u * c->tasks_per_wave), 256u);
+    hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
+                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), EPV_INIT_SWEEP,
+                       c->tasks_per_wave, s0, c->d_counters);
+    hipLaunchKernelGGL(epv_init_commit_kernel, dim3(blocks), dim3(256), 0, c->stream, c->S, colour, first,
+                       last, c->d_counters);
+  }
+  hipLaunchKernelGGL(epv_init_flip_kernel, dim3((unsigned)((last - first + 256u) / 256u)), dim3(256), 0,
+                     c->stream, c->S, first, last);
+  hipLaunchKernelGGL(epv_init_ends_kernel, dim3(1), dim3(64), 0, c->stream, c->S, d_leaf, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), c->blen[1]);
+  HIP_TRY(c, hipGetLastError());
+  rc = finish_mcmc(c, nullptr, 0);  // synchronises; reports capacity overflow
+  (void)hipFree(d_leaf);
+  return rc;
+}
+
 EPV_API int epv_set_global_length(epv_ctx *c, uint64_t n_global) {
   if (!c || !c->have_paths) return EPV_ERR_ARG;
   if (n_global < c->S.g0 + c->S.n) return fail(c, EPV_ERR_ARG, "n_global smaller than the shard");

@@ -814,6 +814,85 @@ __global__ __launch_bounds__(256) void epv_mh_accept_kernel(
 }
 
 // =========================================================================
+//  initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device: every
+//  interior site of a single branch gets an independent end-conditioned path
+//  root[i] -> leaf[i] by forward rejection with the context rates read off the ROOT
+//  sequence.  The device paths start as (init = root, no jumps); per colour (so that the
+//  phase-sized hand-over arrays suffice) epv_init_tasks_kernel lists every site as a
+//  task with end state leaf[i], epv_mh_jumps_kernel -- the very kernel of the MCMC phase,
+//  run with the reserved sweep index EPV_INIT_SWEEP -- draws the jumps into the other
+//  buffer, epv_init_commit_kernel collects overflow flags, and once all three colours are
+//  done epv_init_flip_kernel flips every interior site over to its new path.
+// =========================================================================
+#define EPV_INIT_SWEEP 0xffffffffu
+
+__global__ __launch_bounds__(256) void epv_init_tasks_kernel(EpvDev S, uint32_t colour, uint64_t first,
+                                                             uint64_t last, const uint8_t *leaf,
+                                                             unsigned long long *counters) {
+  const int lane = epv_lane();
+  const uint64_t s0 = first + ((colour + 3u - (uint32_t)((S.g0 + first) % 3u)) % 3u);
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t site = s0 + 3u * tid;
+  const bool valid = site <= last;
+  if (valid) {
+    const uint32_t sel = S.sel[site];
+    const uint32_t root = (uint32_t)(S.meta[meta_idx(S, sel, 0u, site)] >> 7);
+    S.meta[meta_idx(S, sel ^ 1u, 0u, site)] = (uint8_t)(root << 7);
+    S.prop_states[tid * S.W] = leaf[site] ? 1ull : 0ull;
+    S.prop_flag[tid] = 0u;
+  }
+  const uint32_t mine = valid ? 1u : 0u;
+  const uint32_t incl = wave_incl_scan_u32(mine);
+  const uint32_t total = __shfl(incl, 63);
+  if (total) {
+    const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+    unsigned long long base = 0ull;
+    if (lane == 0)
+      base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)], (unsigned long long)total);
+    base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0) << 32) |
+           (unsigned long long)__shfl((uint32_t)base, 0);
+    if (valid) S.tasks[(unsigned long long)shard * S.task_cap + base + (incl - mine)] = site;
+  }
+}
+
+__global__ __launch_bounds__(256) void epv_init_commit_kernel(EpvDev S, uint32_t colour, uint64_t first,
+                                                              uint64_t last,
+                                                              unsigned long long *counters) {
+  const uint64_t s0 = first + ((colour + 3u - (uint32_t)((S.g0 + first) % 3u)) % 3u);
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t site = s0 + 3u * tid;
+  bool overflowed = false;
+  // the flip to the new paths is deferred until every colour has been drawn
+  // (epv_init_flip_kernel): the contexts must come from the ROOT sequence alone, not from
+  // neighbours that already carry their new jumps
+  if (site <= last && S.prop_flag[tid]) overflowed = true;
+  const unsigned long long om = __ballot(overflowed);
+  if (epv_lane() == 0 && om)
+    atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_OVERFLOW, blockIdx.x & (EPV_SHARDS - 1u))],
+              (unsigned long long)__popcll(om));
+  if (blockIdx.x == 0 && threadIdx.x < EPV_SHARDS) counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)] = 0ull;
+}
+
+__global__ __launch_bounds__(256) void epv_init_flip_kernel(EpvDev S, uint64_t first, uint64_t last) {
+  const uint64_t site = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (site <= last) S.sel[site] ^= 1u;
+}
+
+// the two end sites: at most one jump, placed uniformly (epievo_sim_pairwise.cpp:77-88)
+__global__ void epv_init_ends_kernel(EpvDev S, const uint8_t *leaf, uint32_t seed_lo, uint32_t seed_hi,
+                                     double T) {
+  if (threadIdx.x > 1) return;
+  const uint64_t site = threadIdx.x ? S.n - 1u : 0u;
+  const uint32_t sel = S.sel[site];
+  const uint32_t root = (uint32_t)(S.meta[meta_idx(S, sel, 0u, site)] >> 7);
+  if (root != (uint32_t)leaf[site]) {
+    const double u = epv_keyed_block(seed_lo, seed_hi, (uint32_t)(S.g0 + site), EPV_INIT_SWEEP, 1u, 0u, 0u, 0u).d0;
+    S.jumps[((uint64_t)sel * S.B) * S.C * S.n + site] = u * (T - 0.0) + 0.0;
+    S.meta[meta_idx(S, sel, 0u, site)] = (uint8_t)((root << 7) | 1u);
+  }
+}
+
+// =========================================================================
 //  reset: tri[s] = path_log_likelihood(s-1, s, s+1) for every local interior site
 // =========================================================================
 __global__ __launch_bounds__(256) void epv_reset_kernel(EpvDev S) {

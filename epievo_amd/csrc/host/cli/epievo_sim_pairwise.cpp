@@ -2,15 +2,14 @@
 // sample a history on one branch between two observed sequences by `-L` MCMC sweeps.
 // Flags: -L burn-in (10), -T evolutionary time (double, 1.0), -s seed, -o output
 // local_paths (required), -p input paths, -v; positionals <param> <states>.
-// The initial paths (initialize_paths_indep, :62-110) are drawn on the host with this
-// build's own random stream (a device version is "next" row f1 of SURVEY.md section 8).
+// The initial paths (initialize_paths_indep, :62-110) are drawn on the GPU as well
+// (epv_init_paths_indep), so the whole program runs on the device end to end.
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <limits>
 #include <random>
 #include <stdexcept>
-#include <cmath>
 
 #include "epv_io.hpp"
 #include "epv_model.hpp"
@@ -21,51 +20,6 @@ using std::cerr;
 using std::endl;
 using std::string;
 using std::vector;
-
-namespace {
-struct Rng {
-  std::mt19937_64 g;
-  explicit Rng(uint64_t s) : g(s) {}
-  double unif() { return (double)(g() >> 11) * (1.0 / 9007199254740992.0); }
-};
-
-// end_cond_sample_forward_rejection (EndCondSampling.cpp:512-542): forward-simulate a
-// 2-state chain from `a` for time T until it ends in `b`
-void forward_rejection(Rng &rng, double r0, double r1, int a, int b, double T, vector<double> &out) {
-  for (;;) {
-    out.clear();
-    int s = a;
-    double tau = 0.0;
-    while ((tau += -std::log(1.0 - rng.unif()) / (s ? r1 : r0)) < T) { s ^= 1; out.push_back(tau); }
-    if (s == b) return;
-  }
-}
-
-// initialize_paths_indep (epievo_sim_pairwise.cpp:62-110): context rates from the ROOT
-// sequence; the two end sites get at most one uniformly placed jump
-epv::FlatPaths initial_paths(Rng &rng, const vector<uint8_t> &root, const vector<uint8_t> &leaf,
-                             const epv::Model &m, double T) {
-  const size_t n = root.size();
-  epv::FlatPaths fp;
-  fp.n_sites = n;
-  fp.n_nodes = 2;
-  fp.init.assign(root.begin(), root.end());
-  fp.offsets.assign(n + 1, 0);
-  vector<double> js;
-  for (size_t i = 0; i < n; ++i) {
-    fp.offsets[i] = fp.jumps.size();
-    if (i == 0 || i == n - 1) {
-      if (root[i] != leaf[i]) fp.jumps.push_back(rng.unif() * T);
-      continue;
-    }
-    const int c0 = 4 * root[i - 1] + root[i + 1];
-    forward_rejection(rng, m.rates[c0], m.rates[c0 | 2], root[i], leaf[i], T, js);
-    fp.jumps.insert(fp.jumps.end(), js.begin(), js.end());
-  }
-  fp.offsets[n] = fp.jumps.size();
-  return fp;
-}
-}  // namespace
 
 int main(int argc, const char **argv) {
   try {
@@ -99,7 +53,6 @@ int main(int argc, const char **argv) {
 
     if (rng_seed == std::numeric_limits<size_t>::max()) { std::random_device rd; rng_seed = rd(); }
     if (VERBOSE) cerr << "rng seed: " << rng_seed << endl;
-    Rng rng(rng_seed);
 
     epv::Tree th = epv::Tree::single_branch(evolutionary_time);
     vector<string> names;
@@ -109,18 +62,18 @@ int main(int argc, const char **argv) {
     th.node_names = names;
 
     epv::FlatPaths paths;
+    epv::SingleSiteSampler mcmc(burnin, 1);
     if (!pathfile.empty()) {
       vector<string> nn;
       vector<double> tt;
       paths = epv::read_local_paths(pathfile, nn, tt);
       if (paths.n_nodes != 2 || tt[1] != evolutionary_time)
         throw std::runtime_error("input paths do not match a single branch of the given time");
+      mcmc.reset(the_model, th, paths);
     } else {
-      paths = initial_paths(rng, states[0], states[1], the_model, evolutionary_time);
+      mcmc.init_paths_indep(the_model, th, states[0], states[1], rng_seed);
+      paths.n_sites = states[0].size();
     }
-
-    epv::SingleSiteSampler mcmc(burnin, 1);
-    mcmc.reset(the_model, th, paths);
     const size_t n_acc = mcmc.sweeps(burnin, rng_seed, 0);
     if (VERBOSE)
       cerr << "acceptance rate: " << (double)n_acc / ((double)burnin * (paths.n_sites - 2)) << endl;

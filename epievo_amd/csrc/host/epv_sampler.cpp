@@ -32,6 +32,19 @@ void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &p
   reset(m);
 }
 
+void SingleSiteSampler::init_paths_indep(const Model &m, const Tree &th, const std::vector<uint8_t> &root_seq,
+                                         const std::vector<uint8_t> &leaf_seq, uint64_t seed) {
+  if (root_seq.size() != leaf_seq.size()) throw std::runtime_error("sequences differ in length");
+  n_nodes_ = th.n_nodes();
+  n_sites_ = root_seq.size();
+  check(epv_set_tree(ctx_, th.n_nodes(), th.parent_ids.data(), th.subtree_sizes.data(),
+                     th.branches.data()), "epv_set_tree");
+  check(epv_set_model(ctx_, m.rates.data(), m.T.data()), "epv_set_model");
+  check(epv_init_paths_indep(ctx_, root_seq.size(), root_seq.data(), leaf_seq.data(), seed, capacity_),
+        "epv_init_paths_indep");
+  check(epv_reset(ctx_), "epv_reset");
+}
+
 void SingleSiteSampler::reset(const Model &m) {
   check(epv_set_model(ctx_, m.rates.data(), m.T.data()), "epv_set_model");
   check(epv_reset(ctx_), "epv_reset");

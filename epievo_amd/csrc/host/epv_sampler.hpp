@@ -36,6 +36,11 @@ public:
   void reset(const Model &the_model, const Tree &th, const FlatPaths &paths);
   void reset(const Model &the_model);
 
+  // initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device for the
+  // two-node tree `th`; afterwards the paths are resident as after reset(model, th, paths)
+  void init_paths_indep(const Model &the_model, const Tree &th, const std::vector<uint8_t> &root_seq,
+                        const std::vector<uint8_t> &leaf_seq, uint64_t seed);
+
   // SingleSiteSampler::run_mcmc (:550-598).  J/D are resized to n_nodes rows of 8 (row 0
   // empty) and hold batch averages, exactly as the reference returns them.
   void run_mcmc(uint64_t seed, uint64_t em_iteration, std::vector<std::vector<double>> &J_all_sites,

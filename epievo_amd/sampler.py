@@ -35,7 +35,7 @@ class _Counters(C.Structure):
 
 ABI_SYMBOLS = [
     "epv_create", "epv_destroy", "epv_last_error", "epv_set_tree", "epv_set_model",
-    "epv_upload_paths", "epv_set_global_length", "epv_set_update_range", "epv_set_halo",
+    "epv_upload_paths", "epv_init_paths_indep", "epv_set_global_length", "epv_set_update_range", "epv_set_halo",
     "epv_halo_phases_left", "epv_reset", "epv_sweep",
     "epv_sweep_phase", "epv_run_mcmc", "epv_run_mcmc_sums", "epv_get_sufficient_statistics", "epv_scale_jump_times",
     "epv_paths_total_jumps", "epv_download_paths", "epv_get_tri_llh", "epv_column_bytes",
@@ -64,6 +64,7 @@ def lib():
         L.epv_set_tree.argtypes = [vp, C.c_int, u32p, u32p, dp]
         L.epv_set_model.argtypes = [vp, dp, dp]
         L.epv_upload_paths.argtypes = [vp, C.c_uint64, u8p, u64p, dp, C.c_uint32, C.c_uint64]
+        L.epv_init_paths_indep.argtypes = [vp, C.c_uint64, u8p, u8p, C.c_uint64, C.c_uint32]
         L.epv_set_global_length.argtypes = [vp, C.c_uint64]
         L.epv_set_update_range.argtypes = [vp, C.c_uint64, C.c_uint64]
         L.epv_set_halo.argtypes = [vp, C.c_uint64, C.c_uint64]
@@ -134,6 +135,13 @@ class DeviceSampler:
                                          capacity, global_site_offset))
         if n_global is not None:
             self._ck(self.L.epv_set_global_length(self.h, n_global))
+
+    def init_paths_indep(self, root, leaf, seed, capacity=0):
+        root = np.ascontiguousarray(root, np.uint8)
+        leaf = np.ascontiguousarray(leaf, np.uint8)
+        self.n_sites = len(root)
+        self._ck(self.L.epv_init_paths_indep(self.h, len(root), _p(root, C.c_uint8),
+                                             _p(leaf, C.c_uint8), seed, capacity))
 
     def set_update_range(self, first, last):
         self._ck(self.L.epv_set_update_range(self.h, first, last))

@@ -79,6 +79,16 @@ int epv_upload_paths(epv_ctx *ctx, uint64_t n_sites, const uint8_t *init_state,
                      const uint64_t *offsets, const double *jumps, uint32_t capacity,
                      uint64_t global_site_offset);
 
+/* initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device, for the
+ * two-node tree of one branch (epv_set_tree with n_nodes = 2 and epv_set_model first):
+ * every interior site gets an independent end-conditioned path root[i] -> leaf[i] by
+ * forward rejection (EndCondSampling.cpp:512-542) with the context rates read off the
+ * ROOT sequence; the two end sites get at most one uniformly placed jump.  Replaces the
+ * upload: afterwards the paths are resident as if epv_upload_paths had been called.
+ * capacity 0 = 32 jump slots. */
+int epv_init_paths_indep(epv_ctx *ctx, uint64_t n_sites, const uint8_t *root_states,
+                         const uint8_t *leaf_states, uint64_t seed, uint32_t capacity);
+
 /* Site-sharded runs only: total genome length (default: global_site_offset + n_sites),
  * so that the two special cases at the genome ends (SingleSiteSampler.cpp:422,427) are
  * decided on global indices. */

@@ -699,6 +699,56 @@ ORC_API void orc_get_counters(const orc_state *st, uint64_t *out) {
   out[0] = st->n_overflow; out[1] = st->n_trials; out[2] = st->n_draws; out[3] = st->n_segments;
 }
 
+/* ------------------------------------------------ initial paths for one branch
+ * initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110): every site gets an
+ * end-conditioned path root[i] -> leaf[i] on [0,T] drawn independently by forward
+ * rejection (EndCondSampling.cpp:512-542) with the context rates read off the ROOT
+ * sequence; the two end sites get at most one jump, placed uniformly.  Draw order of the
+ * reference (rung A): site 0, site n-1, then sites 1..n-2.  Rung B keys the draws by
+ * (site, sweep = ORC_INIT_SWEEP, branch 1, segment 0).  Output: node-major flat paths of
+ * the two-node tree (init, offsets[n+1], jumps); returns the number of jumps, or the
+ * number needed when `jumps_cap` is too small. */
+#define ORC_INIT_SWEEP 0xffffffffu
+ORC_API uint64_t orc_init_paths_indep(int rng_mode, int math_mode, uint64_t seed, const double *rates,
+                                      uint64_t n, const uint8_t *root, const uint8_t *leaf, double T,
+                                      uint8_t *init, uint64_t *offsets, double *jumps,
+                                      uint64_t jumps_cap) {
+  orc_state st;
+  memset(&st, 0, sizeof(st));
+  st.rng_mode = rng_mode; st.math_mode = math_mode; st.seed = seed; st.cap = 0;
+  set_math(&st);
+  orc_mt_seed(&st.mt, (uint32_t)seed);
+  orc_scratch sc;
+  memset(&sc, 0, sizeof(sc));
+  orc_path *paths = (orc_path *)calloc(n, sizeof(orc_path));
+  orc_rng g;
+  g.st = &st; g.sweep = ORC_INIT_SWEEP;
+  const uint64_t ends[2] = {0, n - 1};
+  for (int e = 0; e < 2; ++e) {
+    const uint64_t s = ends[e];
+    paths[s].init = root[s];
+    g.site = (uint32_t)s;
+    if (root[s] != leaf[s]) path_push(&paths[s], rng_segment_uniform(&g, 1, 0) * (T - 0.0) + 0.0);
+  }
+  for (uint64_t s = 1; s + 1 < n; ++s) {
+    const int c0 = 4 * root[s - 1] + root[s + 1];
+    paths[s].init = root[s];
+    g.site = (uint32_t)s;
+    forward_rejection(&st, &sc, &g, 1, 0, rates[c0], rates[c0 | 2], root[s], leaf[s], T, 0.0, &paths[s]);
+  }
+  uint64_t tot = 0;
+  for (uint64_t s = 0; s < n; ++s) {
+    init[s] = paths[s].init;
+    offsets[s] = tot;
+    for (uint32_t k = 0; k < paths[s].n; ++k, ++tot)
+      if (tot < jumps_cap) jumps[tot] = paths[s].t[k];
+    free(paths[s].t);
+  }
+  offsets[n] = tot;
+  free(paths); free(sc.trial);
+  return tot;
+}
+
 /* ------------------------------------------------- per-function KAT hooks */
 ORC_API void orc_kat_trans_prob_mat(int math_mode, double r0, double r1, double t, double *P) {
   orc_state st; st.math_mode = math_mode; set_math(&st);

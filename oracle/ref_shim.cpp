@@ -11,6 +11,7 @@
  */
 #include <limits>
 #include <random>
+#include <functional>
 #include <vector>
 #include <array>
 #include <string>
@@ -25,6 +26,7 @@
 #include "ContinuousTimeMarkovModel.hpp"
 #include "SingleSiteSampler.hpp"
 #include "ParamEstimation.hpp"
+#include "EndCondSampling.hpp"
 
 using std::vector;
 using std::array;
@@ -224,6 +226,34 @@ double ref_m_step(int optimize_branches, int n_nodes, const double *J, const dou
     param_text[param_text_len - 1] = '\0';
   }
   return llh;
+}
+
+/* the glue of initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) around
+ * the LINKED end_cond_sample_forward_rejection(ctmm, ...) (EndCondSampling.cpp:512-542):
+ * same call order, same std::mt19937 */
+uint64_t ref_init_paths_indep(uint64_t seed, const double *rates, uint64_t n, const uint8_t *root,
+                              const uint8_t *leaf, double T, uint8_t *init, uint64_t *offsets,
+                              double *jumps, uint64_t jumps_cap) {
+  std::mt19937 gen(seed);
+  std::uniform_real_distribution<double> dist(0.0, T);
+  vector<vector<double> > pj(n);
+  if (root[0] != leaf[0]) pj[0].push_back(dist(gen));
+  if (root[n - 1] != leaf[n - 1]) pj[n - 1].push_back(dist(gen));
+  for (uint64_t s = 1; s + 1 < n; ++s) {
+    const size_t p0 = triple2idx(root[s - 1], false, root[s + 1]);
+    const size_t p1 = triple2idx(root[s - 1], true, root[s + 1]);
+    const TwoStateCTMarkovModel ctmm(rates[p0], rates[p1]);
+    end_cond_sample_forward_rejection(ctmm, root[s], leaf[s], T, gen, pj[s], 0.0);
+  }
+  uint64_t tot = 0;
+  for (uint64_t s = 0; s < n; ++s) {
+    init[s] = root[s];
+    offsets[s] = tot;
+    for (size_t k = 0; k < pj[s].size(); ++k, ++tot)
+      if (tot < jumps_cap) jumps[tot] = pj[s][k];
+  }
+  offsets[n] = tot;
+  return tot;
 }
 
 /* ---- per-function known answers */

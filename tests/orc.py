@@ -71,6 +71,8 @@ def orc_lib():
         L.orc_kat_suffstats.argtypes = [C.c_int, C.c_uint32, dp, C.c_int, C.c_uint32, dp, C.c_int,
                                         C.c_uint32, dp, C.c_double, dp, dp]
         L.orc_kat_end_cond_means.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_uint64, dp]
+        L.orc_init_paths_indep.argtypes = [C.c_int, C.c_int, C.c_uint64, dp, C.c_uint64, u8p, u8p, C.c_double, u8p, u64p, dp, C.c_uint64]
+        L.orc_init_paths_indep.restype = C.c_uint64
         L.orc_kat_exp.argtypes = [C.c_double]
         L.orc_kat_exp.restype = C.c_double
         L.orc_kat_log.argtypes = [C.c_double]
@@ -119,6 +121,9 @@ def ref_lib():
                                         C.c_uint32, dp, C.c_double, dp, dp]
         L.ref_kat_expectations.argtypes = [C.c_double, C.c_double, C.c_double, dp]
         L.ref_kat_mt_canonical.argtypes = [C.c_uint64, C.c_uint64, dp]
+        if hasattr(L, 'ref_init_paths_indep'):
+            L.ref_init_paths_indep.argtypes = [C.c_uint64, dp, C.c_uint64, u8p, u8p, C.c_double, u8p, u64p, dp, C.c_uint64]
+            L.ref_init_paths_indep.restype = C.c_uint64
         _ref = L
     return _ref
 
@@ -248,3 +253,28 @@ class Reference(_Engine):
 def paths_equal(a, b):
     return (a.n_sites == b.n_sites and a.n_nodes == b.n_nodes and np.array_equal(a.init, b.init)
             and np.array_equal(a.offsets, b.offsets) and np.array_equal(a.jumps, b.jumps))
+
+
+def init_paths_indep(engine, seed, rates, root, leaf, T, rung="B"):
+    """initialize_paths_indep through the oracle (engine='orc', rung A or B) or the linked
+    reference (engine='ref') -> FlatPaths of the two-node tree"""
+    from epievo_amd.host import FlatPaths
+    n = len(root)
+    root = np.ascontiguousarray(root, np.uint8)
+    leaf = np.ascontiguousarray(leaf, np.uint8)
+    rates = np.ascontiguousarray(rates, np.float64)
+    init, off = np.zeros(n, np.uint8), np.zeros(n + 1, np.uint64)
+    cap = 8 * n + 64
+    jumps = np.zeros(cap)
+    if engine == "ref":
+        tot = ref_lib().ref_init_paths_indep(seed, _p(rates, C.c_double), n, _p(root, C.c_uint8),
+                                             _p(leaf, C.c_uint8), T, _p(init, C.c_uint8),
+                                             _p(off, C.c_uint64), _p(jumps, C.c_double), cap)
+    else:
+        modes = (RNG_MT, MATH_LIBM) if rung == "A" else (RNG_PHILOX, MATH_EPV)
+        tot = orc_lib().orc_init_paths_indep(modes[0], modes[1], seed, _p(rates, C.c_double), n,
+                                             _p(root, C.c_uint8), _p(leaf, C.c_uint8), T,
+                                             _p(init, C.c_uint8), _p(off, C.c_uint64),
+                                             _p(jumps, C.c_double), cap)
+    assert tot <= cap
+    return FlatPaths(n, 2, init, off, jumps[:tot])

@@ -71,6 +71,14 @@ def test_sim_pairwise_runs_and_keeps_end_states(tmp_path):
     assert names == ["root", "leaf"] and tt[1] == 1.0
     assert np.array_equal(out.init, root)
     assert np.array_equal(out.init ^ (out.counts() & 1).astype(np.uint8), leaf)
+    # bit-identical to the oracle: device init (initialize_paths_indep) + 5 sweeps
+    t1 = host.Tree.single_branch(1.0)
+    exp0 = orc.init_paths_indep("orc", 9, model.rates, root, leaf, 1.0, "B")
+    o = orc.Oracle(t1, model, exp0, "B", cap=32, seed=9)
+    o.reset()
+    for w in range(5):
+        o.sweep(w)
+    assert orc.paths_equal(out, o.paths())
     # error behaviour: bad file -> message on stderr, EXIT_FAILURE (main's catch block)
     r = subprocess.run([os.path.join(BIN, "epievo_sim_pairwise"), "-o", d + "/x", d + "/nope", d + "/obs.states"],
                        capture_output=True, text=True)

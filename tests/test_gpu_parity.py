@@ -151,3 +151,25 @@ def test_full_size_properties():
     assert np.allclose(Jn.reshape(B, 8).sum(1), cnt[:, 1:-1].sum(1))
     assert np.allclose(Dn.reshape(B, 8).sum(1), (n - 2) * tree.branches[1:], rtol=1e-12)
     assert 0.9 < nacc / (2.0 * (n - 2)) < 1.0
+
+
+@pytest.mark.parametrize("n,seed", [(5000, 3), (200001, 9), (3, 1), (4, 2)])
+def test_init_paths_indep_bit_exact(n, seed):
+    """epievo_sim_pairwise's initial paths on the device == the oracle's parallel rung"""
+    from epievo_amd import host
+    from epievo_amd.sampler import DeviceSampler
+    model, tree, fp = simulate("pair", n, seed=seed)
+    root = fp.init
+    leaf = fp.init ^ (fp.counts() & 1).astype(np.uint8)
+    d = DeviceSampler(0)
+    d.set_tree(host.Tree.single_branch(1.0))
+    d.set_model(model)
+    d.init_paths_indep(root, leaf, seed=77, capacity=32)
+    exp = orc.init_paths_indep("orc", 77, model.rates, root, leaf, 1.0, "B")
+    assert orc.paths_equal(d.paths(), exp)
+    # and the MCMC can start from them
+    d.reset()
+    o = orc.Oracle(tree, model, exp, "B", cap=32, seed=5)
+    o.reset()
+    assert d.sweep(2, 5) == o.sweep(0) + o.sweep(1)
+    assert orc.paths_equal(d.paths(), o.paths())

@@ -112,3 +112,17 @@ def test_rung_a_vs_linked_reference_live(cfg, n, seed):
     assert np.array_equal(Jo, Jr) and np.array_equal(Do, Dr) and acc == accr
     assert orc.paths_equal(o.paths(), R.paths())
     assert np.array_equal(o.tri_llh(), R.tri_llh())
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+@pytest.mark.parametrize("n,seed", [(2000, 1), (37, 5), (3, 2)])
+def test_init_paths_indep_rung_a_vs_linked_reference(n, seed):
+    """initialize_paths_indep (epievo_sim_pairwise.cpp:62-110): the oracle in
+    reference-schedule mode against the glue around the LINKED forward-rejection sampler"""
+    from common import simulate
+    model, tree, fp = simulate("pair", n, seed=seed)
+    root = fp.init
+    leaf = fp.init ^ (fp.counts() & 1).astype(np.uint8)
+    a = orc.init_paths_indep("orc", seed, model.rates, root, leaf, 1.0, "A")
+    r = orc.init_paths_indep("ref", seed, model.rates, root, leaf, 1.0)
+    assert orc.paths_equal(a, r)
