@@ -205,25 +205,50 @@ FlatPaths read_local_paths(const std::string &path_file, std::vector<std::string
   return fp;
 }
 
+// The EM driver rewrites the whole local_paths file every iteration
+// (epievo_est_params_histories.cpp:280-283): 4e6 lines at n = 1e6.  Lines are assembled
+// by hand into one large buffer per node: the site index by a backwards itoa, the
+// per-branch constant "\t<init>\t<tot_time>\t" from two prebuilt strings, and only actual
+// jump times (5 % of the lines on tree.nwk) go through printf's %.17g -- which is what
+// ostream precision(max_digits10) in the default float format prints (Path.cpp:62-71).
 void write_local_paths(const std::string &path_file, const std::vector<std::string> &node_names,
                        int n_nodes, uint64_t n_sites, const double *tot_times,
                        const uint8_t *init, const uint64_t *offsets, const double *jumps) {
   std::FILE *f = std::fopen(path_file.c_str(), "w");
   if (!f) throw std::runtime_error("bad output file: " + path_file);
-  std::vector<char> buf(1 << 20);
-  std::setvbuf(f, buf.data(), _IOFBF, buf.size());
   std::fprintf(f, "NODE:%s\n", node_names[0].c_str());
-  // ostream precision(max_digits10 = 17) in the default float format is printf %.17g
+  std::vector<char> buf;
+  buf.reserve((size_t)64 << 20);
+  char num[64];
   for (int b = 1; b < n_nodes; ++b) {
     std::fprintf(f, "NODE:%s\n", node_names[b].c_str());
+    std::string tail[2];
+    for (int is = 0; is < 2; ++is) {
+      std::snprintf(num, sizeof num, "\t%d\t%.17g\t", is, tot_times[b]);
+      tail[is] = num;
+    }
+    buf.clear();
     for (uint64_t s = 0; s < n_sites; ++s) {
       const uint64_t e = (uint64_t)(b - 1) * n_sites + s;
-      std::fprintf(f, "%llu\t%d\t%.17g\t", (unsigned long long)s, (int)init[e], tot_times[b]);
-      for (uint64_t j = offsets[e]; j < offsets[e + 1]; ++j) std::fprintf(f, "%.17g\t", jumps[j]);
-      std::fputc('\n', f);
+      char *p = num + sizeof num;
+      uint64_t v = s;
+      do { *--p = (char)('0' + v % 10); v /= 10; } while (v);
+      buf.insert(buf.end(), p, num + sizeof num);
+      const std::string &t = tail[init[e] ? 1 : 0];
+      buf.insert(buf.end(), t.begin(), t.end());
+      for (uint64_t j = offsets[e]; j < offsets[e + 1]; ++j) {
+        const int k = std::snprintf(num, sizeof num, "%.17g\t", jumps[j]);
+        buf.insert(buf.end(), num, num + k);
+      }
+      buf.push_back('\n');
+      if (buf.size() > ((size_t)60 << 20)) {
+        std::fwrite(buf.data(), 1, buf.size(), f);
+        buf.clear();
+      }
     }
+    std::fwrite(buf.data(), 1, buf.size(), f);
   }
-  std::fclose(f);
+  if (std::fclose(f) != 0) throw std::runtime_error("error writing: " + path_file);
 }
 
 void read_states_file(const std::string &states_file, std::vector<std::string> &names,
