@@ -43,6 +43,9 @@
 
 #include "orc_math.h"
 #include "orc_rng.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_API __attribute__((visibility("default")))
 
@@ -88,6 +91,8 @@ typedef struct orc_state {
   double (*fexp)(double);
   double (*flog)(double);
   orc_scratch scr;
+  orc_scratch *thr_scr; /* per-thread scratch for the OpenMP colour phases */
+  int n_thr_scr;
   /* counters */
   uint64_t n_overflow, n_trials, n_draws, n_segments;
 } orc_state;
@@ -269,10 +274,14 @@ static int forward_rejection(orc_state *st, orc_scratch *sc, orc_rng *g,
     int a = start;
     double tau = 0.0;
     int overflow = 0;
+#ifndef _OPENMP
     ++st->n_trials;
+#endif
     for (;;) {
       const double u = rng_trial_canonical(g);
+#ifndef _OPENMP
       ++st->n_draws;
+#endif
       tau += -st->flog(1.0 - u) / (a ? rate1 : rate0);
       if (!(tau < T)) break;
       if (cap && nj >= room) { overflow = 1; break; }
@@ -316,7 +325,9 @@ static int downward_sampling(orc_state *st, size_t site, orc_scratch *sc, orc_rn
       const double u = rng_segment_uniform(g, (uint32_t)node, (uint32_t)i);
       const int sampled = (u > p0);
       log_prob += (sampled == 0) ? st->flog(p0) : st->flog(1.0 - p0);
+#ifndef _OPENMP
       ++st->n_segments;
+#endif
       if (!overflow)
         overflow = forward_rejection(st, sc, g, (uint32_t)node, (uint32_t)i, r0, r1, prev,
                                      sampled, s->len[i], time_passed, pp);
@@ -443,7 +454,13 @@ static int mh_site(orc_state *st, size_t site, uint32_t sweep, orc_scratch *sc) 
   const double u = rng_accept_uniform(&g);
   int accepted = 0;
   if (llr >= 0 || u < st->fexp(llr)) accepted = 1;
-  if (overflow) { accepted = 0; ++st->n_overflow; }
+  if (overflow) {
+    accepted = 0;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+    ++st->n_overflow;
+  }
 
   if (accepted) {
     for (int b = 1; b < st->n_nodes; ++b) {
@@ -525,6 +542,8 @@ ORC_API void orc_destroy(orc_state *st) {
   if (!st) return;
   for (size_t i = 0; i < (size_t)st->n_nodes * st->n_sites; ++i) free(st->paths[i].t);
   scratch_free(&st->scr, st->n_nodes);
+  for (int t = 0; t < st->n_thr_scr; ++t) scratch_free(&st->thr_scr[t], st->n_nodes);
+  free(st->thr_scr);
   free(st->paths); free(st->tri_llh); free(st->parent); free(st->subtree); free(st->blen);
   free(st);
 }
@@ -559,9 +578,39 @@ ORC_API uint64_t orc_sweep(orc_state *st, uint32_t sweep) {
   if (st->schedule == ORC_SCHED_SEQ) {
     for (size_t s = 1; s + 1 < n; ++s) n_acc += (uint64_t)mh_site(st, s, sweep, &st->scr);
   } else {
-    for (size_t c = 0; c < 3; ++c)
-      for (size_t s = 1; s + 1 < n; ++s)
-        if ((st->g0 + s) % 3 == c) n_acc += (uint64_t)mh_site(st, s, sweep, &st->scr);
+    /* sites of one colour are independent and write-disjoint, so a colour phase may run
+     * on all host cores (the "fair" CPU baseline of BASELINE.md section 3 item 2);
+     * counter-based draws make the result identical for any thread count */
+    int n_thr = 1;
+#ifdef _OPENMP
+    n_thr = omp_get_max_threads();
+#endif
+    if (st->rng_mode != ORC_RNG_PHILOX) n_thr = 1;
+    if (n_thr > 1 && st->n_thr_scr < n_thr) {
+      st->thr_scr = (orc_scratch *)realloc(st->thr_scr, sizeof(orc_scratch) * (size_t)n_thr);
+      for (int t = st->n_thr_scr; t < n_thr; ++t) scratch_init(&st->thr_scr[t], st->n_nodes);
+      st->n_thr_scr = n_thr;
+    }
+    for (size_t c = 0; c < 3; ++c) {
+      const size_t s_first = 1 + ((c + 3 - (st->g0 + 1) % 3) % 3);
+      if (n_thr == 1) {
+        for (size_t s = s_first; s + 1 < n; s += 3) n_acc += (uint64_t)mh_site(st, s, sweep, &st->scr);
+      } else {
+        long long acc = 0;
+        const long long cnt = (s_first + 1 < n) ? (long long)((n - 2 - s_first) / 3 + 1) : 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 4096) reduction(+ : acc)
+#endif
+        for (long long i = 0; i < cnt; ++i) {
+          int t = 0;
+#ifdef _OPENMP
+          t = omp_get_thread_num();
+#endif
+          acc += mh_site(st, s_first + 3 * (size_t)i, sweep, &st->thr_scr[t]);
+        }
+        n_acc += (uint64_t)acc;
+      }
+    }
   }
   return n_acc;
 }
