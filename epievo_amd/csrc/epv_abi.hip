@@ -44,7 +44,7 @@ struct epv_ctx {
   double *d_scale = nullptr;
   // launch shape of the MH kernel
   uint32_t mh_threads = 64, pool_entries = 0;
-  uint32_t tasks_per_wave = 16;  // epv_mh_jumps_kernel: lanes of a wave that own a task
+  uint32_t tasks_per_wave = 32;  // epv_mh_jumps_kernel: lanes of a wave that own a task
   double kbar = 0.0;  // mean jumps per (site, branch) of the uploaded paths
   size_t mh_lds = 0;
   // counters / timing

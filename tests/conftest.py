@@ -10,6 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the native pieces are built in-tree by __graft_entry__.build(); make sure they exist
+    # (and are current) wherever the suite runs -- hipcc cross-compiles without a GPU
+    from epievo_amd import _build
+    _build.build_all()
 
 
 @pytest.fixture(scope="session")
