@@ -18,7 +18,15 @@ from epievo_amd.host import FlatPaths
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run_ranks(world, backend, cfg, n_own, burn, batch, iters, port):
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run_ranks(world, backend, cfg, n_own, burn, batch, iters, port=None):
+    port = _free_port()      # a fixed port can still be in TIME_WAIT from the previous run
     out = tempfile.mkdtemp(prefix="epv_shard_")
     procs = []
     for r in range(world):
