@@ -17,6 +17,7 @@
 #define EPV_API extern "C" __attribute__((visibility("default")))
 
 #include "epv_kernels.h"  // all __global__ kernels (single translation unit, no -fgpu-rdc)
+#include "epv_math.h"
 
 struct epv_ctx {
   int device = 0;
@@ -42,6 +43,7 @@ struct epv_ctx {
   uint64_t partial_cap = 0;
   double *d_jd_acc = nullptr;  // [B*16] accumulated over batch sweeps
   double *d_scale = nullptr;
+  EpvIndepConst *d_indep = nullptr;  // [N] constants of the site-independent model
   // launch shape of the MH kernel
   uint32_t mh_threads = 64, pool_entries = 0;
   uint32_t tasks_per_wave = 32;  // epv_mh_jumps_kernel: lanes of a wave that own a task
@@ -195,7 +197,7 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     // a block (4 waves) takes 4*tpw tasks per pass; size the grid for ~1/4 of the worst case
     const uint64_t jb = std::min<uint64_t>((max_tasks / 4u + 4u * tpw - 1u) / (4u * tpw) + 1u, 256u);
     hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
-                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, c->d_counters);
+                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, 0.0, 0.0, c->d_counters);
   }
   hipLaunchKernelGGL(epv_mh_accept_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256),
                      const_lds_bytes(c->S.N), c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
@@ -270,7 +272,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale);
+  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->stream);
@@ -423,7 +425,7 @@ EPV_API int epv_init_paths_indep(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
     const uint64_t jb = std::min<uint64_t>((per_shard + 4u * c->tasks_per_wave - 1u) / (4u * c->tasks_per_wave), 256u);
     hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
                        c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), EPV_INIT_SWEEP,
-                       c->tasks_per_wave, s0, c->d_counters);
+                       c->tasks_per_wave, s0, 0.0, 0.0, c->d_counters);
     hipLaunchKernelGGL(epv_init_commit_kernel, dim3(blocks), dim3(256), 0, c->stream, c->S, colour, first,
                        last, c->d_counters);
   }
@@ -435,6 +437,156 @@ EPV_API int epv_init_paths_indep(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
   rc = finish_mcmc(c, nullptr, 0);  // synchronises; reports capacity overflow
   (void)hipFree(d_leaf);
   return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+//  site-independent model (IndepSite.cpp), used by epievo_initialization
+// ---------------------------------------------------------------------------------------
+namespace {
+// continuous_time_trans_prob_mat + expectation_J/D (ContinuousTimeMarkovModel.cpp:143-226)
+// for every branch, with epv_exp so that the values equal the oracle's parallel rung
+int upload_indep_consts(epv_ctx *c, const double *rates) {
+  if (!(rates[0] > 0.0) || !(rates[1] > 0.0)) return fail(c, EPV_ERR_ARG, "indep rates must be positive");
+  std::vector<EpvIndepConst> k(c->S.N);
+  const double r0 = rates[0], r1 = rates[1];
+  for (uint32_t node = 1; node < c->S.N; ++node) {
+    const double T = c->blen[node];
+    EpvIndepConst &q = k[node];
+    {
+      const double h = 1.0 / epv_exp(T * (r0 + r1));
+      const double denom = r0 + r1;
+      q.P[0] = (r0 * h + r1) / denom;
+      q.P[1] = 1.0 - q.P[0];
+      q.P[3] = (r0 + r1 * h) / denom;
+      q.P[2] = 1.0 - q.P[3];
+    }
+    const double s = r0 + r1, p = r0 * r1, d = r1 - r0;
+    const double e = epv_exp(-s * T);
+    const double C1 = d * (1 - e) / s;
+    q.J0[0] = p * (T * (r1 - r0 * e) - C1) / (s * (r1 + r0 * e));
+    q.J1[0] = q.J0[0];
+    q.J0[3] = p * (T * (r0 - r1 * e) + C1) / (s * (r0 + r1 * e));
+    q.J1[3] = q.J0[3];
+    const double C2 = p * T * (1 + e) / (s * (1 - e));
+    const double C3 = (r0 * r0 + r1 * r1) / (s * s);
+    const double C4 = (2 * p) / (s * s);
+    q.J0[1] = C2 + C3; q.J1[1] = C2 - C4; q.J0[2] = q.J1[1]; q.J1[2] = q.J0[1];
+    const double r00 = r0 * r0, r11 = r1 * r1;
+    const double E1 = 2 * p * (1 - e) / s;
+    q.D0[0] = ((r11 + r00 * e) * T + E1) / (s * (r1 + r0 * e));
+    q.D1[0] = T - q.D0[0];
+    q.D1[3] = ((r00 + r11 * e) * T + E1) / (s * (r0 + r1 * e));
+    q.D0[3] = T - q.D1[3];
+    const double E2 = (p - r00) * (1 - e) / s;
+    q.D1[1] = ((r00 - p * e) * T + E2) / (s * (r0 - r0 * e));
+    q.D0[1] = T - q.D1[1];
+    const double E3 = (p - r11) * (1 - e) / s;
+    q.D0[2] = ((r11 - p * e) * T + E3) / (s * (r1 - r1 * e));
+    q.D1[2] = T - q.D0[2];
+  }
+  if (!c->d_indep) HIP_TRY(c, hipMalloc(&c->d_indep, sizeof(EpvIndepConst) * c->S.N));
+  HIP_TRY(c, hipMemcpy(c->d_indep, k.data(), sizeof(EpvIndepConst) * c->S.N, hipMemcpyHostToDevice));
+  return EPV_OK;
+}
+
+int indep_stats(epv_ctx *c, const double *rates, uint32_t what, double *J, double *D) {
+  const uint32_t B = c->S.B, V16 = ((B * 4u + 15u) / 16u) * 16u;
+  // 256-lane blocks when the per-node LDS table fits, 64-lane blocks for large trees
+  uint32_t threads = 256u;
+  size_t lds = (size_t)c->S.N * threads * 5u * sizeof(double);
+  if (lds > 60u * 1024u) { threads = 64u; lds = (size_t)c->S.N * threads * 5u * sizeof(double); }
+  const uint64_t nb = (c->S.n + threads - 1u) / threads;
+  // the tree-reduction buffers are shared with the 8-context statistics (16 columns per
+  // branch and 256 sites per block there, so they are large enough for both shapes)
+  int rc = ensure_partials(c);
+  if (rc) return rc;
+  if (lds > 150u * 1024u) return fail(c, EPV_ERR_ARG, "tree too large for the site-independent kernels");
+  if (lds > 60u * 1024u &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(epv_indep_stats_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(c, EPV_ERR_HIP, "cannot raise the dynamic LDS limit");
+  double pi_0 = 0.0;
+  if (what == 0u) pi_0 = rates[1] / (rates[0] + rates[1]);
+  hipLaunchKernelGGL(epv_indep_stats_kernel, dim3((unsigned)nb), dim3(threads), lds, c->stream, c->S, c->d_indep,
+                     pi_0, what, V16, c->d_partial[0]);
+  uint64_t m = nb;
+  int cur = 0;
+  while (m > 1) {
+    const uint64_t mb = (m + 255u) / 256u;
+    hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb), dim3(256), 0, c->stream, c->d_partial[cur], m,
+                       V16, c->d_partial[cur ^ 1]);
+    m = mb;
+    cur ^= 1;
+  }
+  HIP_TRY(c, hipGetLastError());
+  std::vector<double> v(V16);
+  HIP_TRY(c, hipMemcpyAsync(v.data(), c->d_partial[cur], V16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t b = 0; b < B; ++b) {
+    J[b * 2 + 0] = v[b * 4 + 0]; J[b * 2 + 1] = v[b * 4 + 1];
+    D[b * 2 + 0] = v[b * 4 + 2]; D[b * 2 + 1] = v[b * 4 + 3];
+  }
+  return EPV_OK;
+}
+}  // namespace
+
+EPV_API int epv_indep_expectation(epv_ctx *c, const double *rates, double *J, double *D) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (!rates || !J || !D) return fail(c, EPV_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if ((rc = upload_indep_consts(c, rates))) return rc;
+  return indep_stats(c, rates, 0u, J, D);
+}
+
+EPV_API int epv_indep_sufficient_statistics(epv_ctx *c, double *J, double *D) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (!J || !D) return fail(c, EPV_ERR_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const double one[2] = {1.0, 1.0};
+  if ((rc = upload_indep_consts(c, one))) return rc;   // constants unused by the counting mode
+  if ((rc = indep_stats(c, one, 1u, J, D))) return rc;
+  for (uint32_t i = 0; i < 2u * c->S.B; ++i) {   // averages over the sites (IndepSite.cpp:291-295)
+    J[i] /= (double)c->S.n;
+    D[i] /= (double)c->S.n;
+  }
+  return EPV_OK;
+}
+
+EPV_API int epv_indep_update_paths(epv_ctx *c, const double *rates, uint64_t seed, uint32_t sweep) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (!rates) return fail(c, EPV_ERR_ARG, "null argument");
+  if (c->S.g0 != 0) return fail(c, EPV_ERR_ARG, "epv_indep_update_paths works on an unsharded genome");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if ((rc = upload_indep_consts(c, rates))) return rc;
+  const uint64_t first = 0, last = c->S.n - 1;
+  const uint64_t threads = (last - first + 1u + 2u) / 3u;
+  const size_t lds = (size_t)c->S.N * 64u * 4u * sizeof(double);
+  if (lds > 150u * 1024u) return fail(c, EPV_ERR_ARG, "tree too large for the site-independent kernels");
+  if (lds > 60u * 1024u &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(epv_indep_propose_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(c, EPV_ERR_HIP, "cannot raise the dynamic LDS limit");
+  for (uint32_t colour = 0; colour < 3; ++colour) {
+    const uint64_t s0 = first + ((colour + 3u - (uint32_t)((c->S.g0 + first) % 3u)) % 3u);
+    const uint64_t blocks = (threads + 63u) / 64u;
+    hipLaunchKernelGGL(epv_indep_propose_kernel, dim3((unsigned)blocks), dim3(64), lds, c->stream, c->S,
+                       c->d_indep, rates[0], rates[1], colour, first, last, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), sweep, c->d_counters);
+    const uint64_t max_tasks = blocks / EPV_SHARDS * 64u * c->S.B + 64u * c->S.B;
+    const uint32_t tpw = c->tasks_per_wave;
+    const uint64_t jb = std::min<uint64_t>((max_tasks / 4u + 4u * tpw - 1u) / (4u * tpw) + 1u, 256u);
+    hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
+                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, rates[0],
+                       rates[1], c->d_counters);
+    hipLaunchKernelGGL(epv_indep_commit_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256), 0,
+                       c->stream, c->S, colour, first, last, c->d_counters);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->have_reset = false;
+  return finish_mcmc(c, nullptr, 0);
 }
 
 EPV_API int epv_set_global_length(epv_ctx *c, uint64_t n_global) {

@@ -51,6 +51,14 @@ struct EpvDev {
   const double *blen;          // [N]
 };
 
+// Site-independent model (IndepSite.cpp): per-node constants evaluated once on the host
+// with epv_exp -- every site shares the two rates, so the per-site kernels need no
+// transcendental at all.  2x2 matrices row-major {00,01,10,11}.
+struct EpvIndepConst {
+  double P[4];                     // continuous_time_trans_prob_mat(r0, r1, branch length)
+  double J0[4], J1[4], D0[4], D1[4];  // expectation_J / expectation_D
+};
+
 // counters[] slots
 enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_N = 4 };
 // Every counter is sharded 64 ways with a 128-byte stride (one device-scope atomic word

@@ -61,6 +61,29 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
   return epv_u2d(((uint64_t)hi << 32) | lo);
 }
 
+// Sum 16 per-lane values over the wave in the canonical balanced-tree order with a
+// transpose-reduce: at stage s (xor 1,2,4,8) a lane keeps half of its values and
+// trades the other half with its partner, so the 16 butterflies of 6 stages each (96
+// shuffles + 96 adds) become 8+4+2+1 exchanges plus two full-width stages.  Every
+// individual sum still pairs lanes (i, i^1), then (i, i^2), ... exactly as the plain
+// xor butterfly does, so the result is bit-identical to it.  On return lane l holds
+// the wave total of value index idx(l) = 8*bit0 + 4*bit1 + 2*bit2 + bit3 of l.
+__device__ __forceinline__ double wave_tree_sum16(const double v[16], int lane, int &idx) {
+  double w[8], x[4], y[2], z;
+  const bool h0 = lane & 1, h1 = lane & 2, h2 = lane & 4, h3 = lane & 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = (h0 ? v[i + 8] : v[i]) + shfl_xor_f64(h0 ? v[i] : v[i + 8], 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = (h1 ? w[i + 4] : w[i]) + shfl_xor_f64(h1 ? w[i] : w[i + 4], 2);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) y[i] = (h2 ? x[i + 2] : x[i]) + shfl_xor_f64(h2 ? x[i] : x[i + 2], 4);
+  z = (h3 ? y[1] : y[0]) + shfl_xor_f64(h3 ? y[0] : y[1], 8);
+  z = z + shfl_xor_f64(z, 16);
+  z = z + shfl_xor_f64(z, 32);
+  idx = (h0 ? 8 : 0) + (h1 ? 4 : 0) + (h2 ? 2 : 0) + (h3 ? 1 : 0);
+  return z;
+}
+
 // ------------------------------------------------------------------ path access
 // meta is SITE-major: the B bytes of one site's column sit together, so the branches of a
 // column come out of one cache line (one dword for tree.nwk's four branches)
@@ -563,6 +586,7 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
 __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
                                                            uint32_t seed_hi, uint32_t sweep,
                                                            uint32_t tasks_per_wave, uint64_t s0,
+                                                           double indep_r0, double indep_r1,
                                                            unsigned long long *counters) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   // per-wave cooperative-search area: task slots by rank and per-lane trial results
@@ -576,6 +600,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
   double *c_len = c_len_[wave], *c_r0 = c_r0_[wave], *c_r1 = c_r1_[wave], *c_tj = c_tj_[wave];
   uint32_t *c_misc = c_misc_[wave], *c_gsite = c_gsite_[wave], *c_tbase = c_tbase_[wave],
            *c_nk = c_nk_[wave], *c_res = c_res_[wave], *c_tw = c_tw_[wave];
+  const bool indep = indep_r0 > 0.0;   // epv_indep_update_paths: rates are not context dependent
   const uint32_t shard = blockIdx.y;   // one task-list region per counter shard
   const unsigned long long n_tasks = counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)];
   const unsigned long long *tasks = S.tasks + (unsigned long long)shard * S.task_cap;
@@ -608,9 +633,11 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
       b = (uint32_t)(task >> 40);
       node = b + 1u;
       gsite = (uint32_t)(S.g0 + site);
-      const uint32_t selL = S.sel[site - 1], selP = S.sel[site] ^ 1u, selR = S.sel[site + 1];
-      L = path_ref(S, selL, b, site - 1);
-      R = path_ref(S, selR, b, site + 1);
+      const uint32_t selP = S.sel[site] ^ 1u;
+      if (!indep) {   // the site-independent model has one segment per branch, no context
+        L = path_ref(S, S.sel[site - 1], b, site - 1);
+        R = path_ref(S, S.sel[site + 1], b, site + 1);
+      }
       ptid = (site - s0) / 3u;
       states = S.prop_states + ((uint64_t)b * S.phase_cap + ptid) * S.W;
       meta = S.meta + meta_idx(S, selP, b, site);
@@ -633,7 +660,8 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
         seg_end = last ? s_blen[node] : (take_left ? tl : tr);
         len = seg_end - seg_start;
         sampled = (uint32_t)(word >> (k & 63u)) & 1u;
-        r0 = s_rates[trip0]; r1 = s_rates[trip0 | 2u];
+        r0 = indep ? indep_r0 : s_rates[trip0];
+        r1 = indep ? indep_r1 : s_rates[trip0 | 2u];
         if (!ovf) {
           uint32_t njt, tw;
           const int oc = scan_trials(seed_lo, seed_hi, gsite, sweep, node, k, 1u, EPV_INLINE_TRIALS, prev,
@@ -893,6 +921,206 @@ __global__ void epv_init_ends_kernel(EpvDev S, const uint8_t *leaf, uint32_t see
 }
 
 // =========================================================================
+//  Site-independent model (IndepSite.cpp), used by epievo_initialization.  One lane per
+//  site; per-node Felsenstein values {q0,q1,p0,p1} in LDS [node][lane]; the per-branch
+//  matrices come from EpvIndepConst, so there is no exp/log on this path.
+// =========================================================================
+__device__ __forceinline__ void indep_upward(const EpvDev &S, const EpvIndepConst *ic, uint32_t sel,
+                                             uint64_t site, double *fh /* [N][blockDim][4] */) {
+  // upward_process (IndepSite.cpp:53-96)
+  const uint32_t T = blockDim.x, t = threadIdx.x;
+  for (uint32_t node = S.N; node-- > 0u;) {
+    double a = 1.0, b = 1.0;
+    const uint32_t sub = S.subtree[node];
+    if (sub == 1u) {
+      const uint32_t m = S.meta[meta_idx(S, sel, node - 1u, site)];
+      const uint32_t leaf_state = (m >> 7) ^ (m & 1u);
+      a = leaf_state ? 0.0 : 1.0;
+      b = leaf_state ? 1.0 : 0.0;
+    } else {
+      for (uint32_t ch = 1u; ch < sub; ch += S.subtree[node + ch]) {
+        const double *c = fh + ((size_t)(node + ch) * T + t) * 4u;
+        a *= c[2];
+        b *= c[3];
+      }
+    }
+    double *me = fh + ((size_t)node * T + t) * 4u;
+    me[0] = a; me[1] = b;
+    if (node == 0u) continue;
+    const double *P = ic[node].P;
+    me[2] = P[0] * a + P[1] * b;
+    me[3] = P[2] * a + P[3] * b;
+  }
+}
+
+// expectation_sufficient_statistics (IndepSite.cpp:98-175, :222-238): per branch the
+// conditional means {J0, J1, D0, D1} of every site, reduced in the canonical tree order.
+// partial layout [block][V16], column 4*(node-1) + {0,1,2,3}, zero padded to V16.
+// what = 0: conditional expectations; what = 1: counts of the current paths
+// (compute_sufficient_statistics, :266-297).
+__global__ __launch_bounds__(256) void epv_indep_stats_kernel(EpvDev S, const EpvIndepConst *ic,
+                                                              double pi_0, uint32_t what, uint32_t V16,
+                                                              double *partial) {
+  extern __shared__ __attribute__((aligned(16))) double fh[];
+  __shared__ double s_part[2][4][16];
+  const int lane = epv_lane();
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = site < S.n;
+  const uint32_t sel = on ? S.sel[site] : 0u;
+  double *pm = fh + (size_t)S.N * blockDim.x * 4u;   // [N][blockDim] marginal P(state 0)
+  if (on && what == 0u) {
+    indep_upward(S, ic, sel, site, fh);
+    const double *root = fh + (size_t)threadIdx.x * 4u;
+    const double a = pi_0 * root[0], b = (1 - pi_0) * root[1];
+    pm[threadIdx.x] = a / (a + b);   // root_post_prob0 (:98-104)
+  }
+  for (uint32_t g = 0; g < V16 / 16u; ++g) {
+    double v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t node = g * 4u + (uint32_t)q + 1u;
+      if (!on || node >= S.N) continue;
+      double j0 = 0.0, j1 = 0.0, d0 = 0.0, d1 = 0.0;
+      if (what == 0u) {
+        // joint_post + weighted_J_D_branch (:106-152)
+        const double *me = fh + ((size_t)node * blockDim.x + threadIdx.x) * 4u;
+        const EpvIndepConst &k = ic[node];
+        const double p0u = pm[(size_t)S.parent[node] * blockDim.x + threadIdx.x];
+        double pj[4];
+        pj[0] = k.P[0] * me[0] * p0u / me[2];
+        pj[1] = k.P[1] * me[1] * p0u / me[2];
+        pj[2] = k.P[2] * me[0] * (1 - p0u) / me[3];
+        pj[3] = k.P[3] * me[1] * (1 - p0u) / me[3];
+        const double Z = pj[0] + pj[1] + pj[2] + pj[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pj[i] /= Z;
+        pm[(size_t)node * blockDim.x + threadIdx.x] = pj[0] + pj[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          j0 += pj[i] * k.J0[i];
+          j1 += pj[i] * k.J1[i];
+          d0 += pj[i] * k.D0[i];
+          d1 += pj[i] * k.D1[i];
+        }
+      } else {
+        const PathRef p = path_ref(S, sel, node - 1u, site);
+        uint32_t prev = p.init;
+        double time = 0.0;
+        for (uint32_t jx = 0; jx < p.nj; ++jx) {
+          const double tj = p.j[(uint64_t)jx * S.n];
+          if (prev) { j1 += 1; d1 += (tj - time); } else { j0 += 1; d0 += (tj - time); }
+          prev ^= 1u;
+          time = tj;
+        }
+        if (prev) d1 += (S.blen[node] - time); else d0 += (S.blen[node] - time);
+      }
+      v[4 * q + 0] = j0; v[4 * q + 1] = j1; v[4 * q + 2] = d0; v[4 * q + 3] = d1;
+    }
+    int idx;
+    const double tot = wave_tree_sum16(v, lane, idx);
+    if (lane < 16) s_part[g & 1u][wave][idx] = tot;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      // blocks are 256 lanes (4 waves) or, for large trees, 64 lanes (1 wave): any
+      // power-of-two grouping is a level of the same balanced binary tree
+      const double(*p)[16] = s_part[g & 1u];
+      partial[(uint64_t)blockIdx.x * V16 + g * 16u + threadIdx.x] =
+          (blockDim.x == 64u) ? p[0][threadIdx.x]
+                              : (p[0][threadIdx.x] + p[1][threadIdx.x]) + (p[2][threadIdx.x] + p[3][threadIdx.x]);
+    }
+  }
+}
+
+// update_paths_indep (IndepSite.cpp:177-215, :241-259), part 1: end state of every
+// branch; clean branches (state kept, provably no jump in trial 1) are final, the rest
+// goes to epv_mh_jumps_kernel (run with the two context-free rates).  Processed in three
+// thirds of the sites so that the phase-sized hand-over arrays suffice.
+__global__ __launch_bounds__(64) void epv_indep_propose_kernel(EpvDev S, const EpvIndepConst *ic,
+                                                              double r0, double r1, uint32_t colour,
+                                                              uint64_t first, uint64_t last,
+                                                              uint32_t seed_lo, uint32_t seed_hi,
+                                                              uint32_t sweep,
+                                                              unsigned long long *counters) {
+  extern __shared__ __attribute__((aligned(16))) double fh[];
+  const int lane = epv_lane();
+  const uint64_t s0 = first + ((colour + 3u - (uint32_t)((S.g0 + first) % 3u)) % 3u);
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t site = s0 + 3u * tid;
+  const bool valid = site <= last;
+  unsigned long long dirty = 0ull;
+  uint32_t sel = 0, root_state = 0;
+  if (valid) {
+    sel = S.sel[site];
+    indep_upward(S, ic, sel, site, fh);
+    root_state = (uint32_t)(S.meta[meta_idx(S, sel, 0u, site)] >> 7);
+    S.prop_flag[tid] = 0u;
+  }
+  const uint32_t gsite = (uint32_t)(S.g0 + site);
+  for (uint32_t node = 1u; node < S.N; ++node) {
+    const uint32_t b = node - 1u;
+    if (valid) {
+      double *me = fh + ((size_t)node * blockDim.x + threadIdx.x) * 4u;
+      const uint32_t par = S.parent[node];
+      const uint32_t start =
+          (par == 0u) ? root_state : (uint32_t)epv_d2u(fh[((size_t)par * blockDim.x + threadIdx.x) * 4u + 2u]);
+      const double *P = ic[node].P;
+      const double pr0 = P[2u * start] * me[0] / (start ? me[3] : me[2]);
+      const epv_block2 sblk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, 0u, 0u, 0u);
+      const uint32_t sampled = (sblk.d0 > pr0) ? 1u : 0u;
+      const bool clean = (sampled == start) &&
+                         (1.0 - sblk.d1 < nojump_bound(S.blen[node] * (start ? r1 : r0)));
+      S.prop_states[((uint64_t)b * S.phase_cap + tid) * S.W] = sampled;
+      S.meta[meta_idx(S, sel ^ 1u, b, site)] = (uint8_t)(start << 7);
+      me[2] = epv_u2d((uint64_t)sampled);   // proposal end state for the children
+      if (!clean) dirty |= 1ull << (b & 63u);
+    }
+    if ((b & 63u) == 63u || node + 1u == S.N) {
+      const uint32_t mine = (uint32_t)__popcll(dirty);
+      const uint32_t incl_t = wave_incl_scan_u32(mine);
+      const uint32_t total = __shfl(incl_t, 63);
+      if (total) {
+        unsigned long long base = 0ull;
+        const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+        if (lane == 0)
+          base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)], (unsigned long long)total);
+        base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0) << 32) |
+               (unsigned long long)__shfl((uint32_t)base, 0);
+        unsigned long long slot = (unsigned long long)shard * S.task_cap + base + (incl_t - mine);
+        unsigned long long d = dirty;
+        while (d) {
+          const uint32_t bit = (uint32_t)(__ffsll((long long)d) - 1);
+          d &= d - 1ull;
+          S.tasks[slot++] = ((unsigned long long)((b & ~63u) + bit) << 40) | site;
+        }
+      }
+      dirty = 0ull;
+    }
+  }
+}
+
+// part 3: the new paths always replace the old ones (this is direct sampling, not MH)
+__global__ __launch_bounds__(256) void epv_indep_commit_kernel(EpvDev S, uint32_t colour, uint64_t first,
+                                                               uint64_t last,
+                                                               unsigned long long *counters) {
+  const uint64_t s0 = first + ((colour + 3u - (uint32_t)((S.g0 + first) % 3u)) % 3u);
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t site = s0 + 3u * tid;
+  bool overflowed = false;
+  if (site <= last) {
+    if (S.prop_flag[tid]) overflowed = true;
+    else S.sel[site] ^= 1u;
+  }
+  const unsigned long long om = __ballot(overflowed);
+  if (epv_lane() == 0 && om)
+    atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_OVERFLOW, blockIdx.x & (EPV_SHARDS - 1u))],
+              (unsigned long long)__popcll(om));
+  if (blockIdx.x == 0 && threadIdx.x < EPV_SHARDS) counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)] = 0ull;
+}
+
+// =========================================================================
 //  reset: tri[s] = path_log_likelihood(s-1, s, s+1) for every local interior site
 // =========================================================================
 __global__ __launch_bounds__(256) void epv_reset_kernel(EpvDev S) {
@@ -915,29 +1143,6 @@ __global__ __launch_bounds__(256) void epv_reset_kernel(EpvDev S) {
 //  local site index (lane butterfly -> 4 waves through LDS -> block partials ->
 //  epv_tree_reduce_kernel levels).  partial layout: [block][b][16] (J then D).
 // =========================================================================
-
-// Sum 16 per-lane values over the wave in the canonical balanced-tree order with a
-// transpose-reduce: at stage s (xor 1,2,4,8) a lane keeps half of its values and
-// trades the other half with its partner, so the 16 butterflies of 6 stages each (96
-// shuffles + 96 adds) become 8+4+2+1 exchanges plus two full-width stages.  Every
-// individual sum still pairs lanes (i, i^1), then (i, i^2), ... exactly as the plain
-// xor butterfly does, so the result is bit-identical to it.  On return lane l holds
-// the wave total of value index idx(l) = 8*bit0 + 4*bit1 + 2*bit2 + bit3 of l.
-__device__ __forceinline__ double wave_tree_sum16(const double v[16], int lane, int &idx) {
-  double w[8], x[4], y[2], z;
-  const bool h0 = lane & 1, h1 = lane & 2, h2 = lane & 4, h3 = lane & 8;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) w[i] = (h0 ? v[i + 8] : v[i]) + shfl_xor_f64(h0 ? v[i] : v[i + 8], 1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = (h1 ? w[i + 4] : w[i]) + shfl_xor_f64(h1 ? w[i] : w[i + 4], 2);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) y[i] = (h2 ? x[i + 2] : x[i]) + shfl_xor_f64(h2 ? x[i] : x[i + 2], 4);
-  z = (h3 ? y[1] : y[0]) + shfl_xor_f64(h3 ? y[0] : y[1], 8);
-  z = z + shfl_xor_f64(z, 16);
-  z = z + shfl_xor_f64(z, 32);
-  idx = (h0 ? 8 : 0) + (h1 ? 4 : 0) + (h2 ? 2 : 0) + (h3 ? 1 : 0);
-  return z;
-}
 
 __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t first,
                                                            uint64_t last, double *partial) {

@@ -15,10 +15,12 @@
 
 #include <stdint.h>
 
-#define EPV_DEV __device__ __forceinline__
+// host + device: the ABI glue evaluates per-branch constants of the site-independent
+// model with the very same functions the kernels use
+#define EPV_DEV __host__ __device__ __forceinline__
 
-EPV_DEV uint64_t epv_d2u(double x) { return (uint64_t)__double_as_longlong(x); }
-EPV_DEV double epv_u2d(uint64_t u) { return __longlong_as_double((long long)u); }
+EPV_DEV uint64_t epv_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
+EPV_DEV double epv_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 
 // log(x), x = 2^e * m, m in [sqrt(1/2), sqrt(2)); f = m - 1; s = f/(2+f);
 // log(1+f) = f - s*(f - R(s^2)), R(z) = sum_{k>=1} 2 z^k/(2k+1) (11 terms)

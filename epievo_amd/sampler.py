@@ -35,7 +35,8 @@ class _Counters(C.Structure):
 
 ABI_SYMBOLS = [
     "epv_create", "epv_destroy", "epv_last_error", "epv_set_tree", "epv_set_model",
-    "epv_upload_paths", "epv_init_paths_indep", "epv_set_global_length", "epv_set_update_range", "epv_set_halo",
+    "epv_upload_paths", "epv_init_paths_indep", "epv_indep_expectation",
+    "epv_indep_sufficient_statistics", "epv_indep_update_paths", "epv_set_global_length", "epv_set_update_range", "epv_set_halo",
     "epv_halo_phases_left", "epv_reset", "epv_sweep",
     "epv_sweep_phase", "epv_run_mcmc", "epv_run_mcmc_sums", "epv_get_sufficient_statistics", "epv_scale_jump_times",
     "epv_paths_total_jumps", "epv_download_paths", "epv_get_tri_llh", "epv_column_bytes",
@@ -65,6 +66,9 @@ def lib():
         L.epv_set_model.argtypes = [vp, dp, dp]
         L.epv_upload_paths.argtypes = [vp, C.c_uint64, u8p, u64p, dp, C.c_uint32, C.c_uint64]
         L.epv_init_paths_indep.argtypes = [vp, C.c_uint64, u8p, u8p, C.c_uint64, C.c_uint32]
+        L.epv_indep_expectation.argtypes = [vp, dp, dp, dp]
+        L.epv_indep_sufficient_statistics.argtypes = [vp, dp, dp]
+        L.epv_indep_update_paths.argtypes = [vp, dp, C.c_uint64, C.c_uint32]
         L.epv_set_global_length.argtypes = [vp, C.c_uint64]
         L.epv_set_update_range.argtypes = [vp, C.c_uint64, C.c_uint64]
         L.epv_set_halo.argtypes = [vp, C.c_uint64, C.c_uint64]
@@ -142,6 +146,21 @@ class DeviceSampler:
         self.n_sites = len(root)
         self._ck(self.L.epv_init_paths_indep(self.h, len(root), _p(root, C.c_uint8),
                                              _p(leaf, C.c_uint8), seed, capacity))
+
+    def indep_expectation(self, rates):
+        r = np.ascontiguousarray(rates, np.float64)
+        J, D = np.zeros(self.B * 2), np.zeros(self.B * 2)
+        self._ck(self.L.epv_indep_expectation(self.h, _p(r, C.c_double), _p(J, C.c_double), _p(D, C.c_double)))
+        return J, D
+
+    def indep_suffstats(self):
+        J, D = np.zeros(self.B * 2), np.zeros(self.B * 2)
+        self._ck(self.L.epv_indep_sufficient_statistics(self.h, _p(J, C.c_double), _p(D, C.c_double)))
+        return J, D
+
+    def indep_update_paths(self, rates, seed, sweep=0):
+        r = np.ascontiguousarray(rates, np.float64)
+        self._ck(self.L.epv_indep_update_paths(self.h, _p(r, C.c_double), seed, sweep))
 
     def set_update_range(self, first, last):
         self._ck(self.L.epv_set_update_range(self.h, first, last))

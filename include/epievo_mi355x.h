@@ -89,6 +89,18 @@ int epv_upload_paths(epv_ctx *ctx, uint64_t n_sites, const uint8_t *init_state,
 int epv_init_paths_indep(epv_ctx *ctx, uint64_t n_sites, const uint8_t *root_states,
                          const uint8_t *leaf_states, uint64_t seed, uint32_t capacity);
 
+/* ---- the site-independent 2-rate model of epievo_initialization (IndepSite.hpp:40-72);
+ * rates = {r0, r1}; J/D laid out [(b-1)*2 + state].
+ * epv_indep_expectation            expectation_sufficient_statistics (IndepSite.cpp:222-238):
+ *                                  conditional means summed over ALL sites
+ * epv_indep_sufficient_statistics  compute_sufficient_statistics (:266-297): per-branch
+ *                                  averages of the resident paths
+ * epv_indep_update_paths           update_paths_indep (:241-259): fresh end-conditioned paths
+ *                                  for every site; `sweep` keys the random stream */
+int epv_indep_expectation(epv_ctx *ctx, const double *rates, double *J, double *D);
+int epv_indep_sufficient_statistics(epv_ctx *ctx, double *J, double *D);
+int epv_indep_update_paths(epv_ctx *ctx, const double *rates, uint64_t seed, uint32_t sweep);
+
 /* Site-sharded runs only: total genome length (default: global_site_offset + n_sites),
  * so that the two special cases at the genome ends (SingleSiteSampler.cpp:422,427) are
  * decided on global indices. */

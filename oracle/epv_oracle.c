@@ -748,6 +748,207 @@ ORC_API void orc_get_counters(const orc_state *st, uint64_t *out) {
   out[0] = st->n_overflow; out[1] = st->n_trials; out[2] = st->n_draws; out[3] = st->n_segments;
 }
 
+/* ------------------------------------------------ site-independent model (IndepSite.cpp)
+ * Used by epievo_initialization to fit a context-free 2-rate model and to draw the
+ * initial histories of the MCEM.  rates = {r0, r1}.  J/D layouts: [(b-1)*2 + state]. */
+
+/* upward_process (IndepSite.cpp:53-96): q per node, p per non-root node; one segment per
+ * branch, no neighbour context */
+static void indep_upward(const orc_state *st, const double *rates, size_t site, double *q0,
+                         double *q1, double *p0, double *p1) {
+  for (int node = st->n_nodes - 1; node >= 0; --node) {
+    double a = 1.0, b = 1.0;
+    if (is_leaf(st, node)) {
+      const int leaf_state = path_end_state(PATH(st, node, site));
+      a = leaf_state ? 0.0 : 1.0;
+      b = leaf_state ? 1.0 : 0.0;
+    } else {
+      for (uint32_t ch = 1; ch < st->subtree[node]; ch += st->subtree[node + ch]) {
+        a *= p0[node + ch];
+        b *= p1[node + ch];
+      }
+    }
+    q0[node] = a; q1[node] = b;
+    if (node == 0) continue;
+    double P[4];
+    trans_prob_mat(st, rates[0], rates[1], st->blen[node], P);
+    p0[node] = P[0] * a + P[1] * b;
+    p1[node] = P[2] * a + P[3] * b;
+  }
+}
+
+/* expectation_J / expectation_D (ContinuousTimeMarkovModel.cpp:168-226) */
+static void expectation_JD(const orc_state *st, double r0, double r1, double T, double J0[4],
+                           double J1[4], double D0[4], double D1[4]) {
+  const double s = r0 + r1, p = r0 * r1, d = r1 - r0;
+  const double e = st->fexp(-s * T);
+  const double C1 = d * (1 - e) / s;
+  J0[0] = p * (T * (r1 - r0 * e) - C1) / (s * (r1 + r0 * e));
+  J1[0] = J0[0];
+  J0[3] = p * (T * (r0 - r1 * e) + C1) / (s * (r0 + r1 * e));
+  J1[3] = J0[3];
+  const double C2 = p * T * (1 + e) / (s * (1 - e));
+  const double C3 = (r0 * r0 + r1 * r1) / (s * s);
+  const double C4 = (2 * p) / (s * s);
+  J0[1] = C2 + C3; J1[1] = C2 - C4; J0[2] = J1[1]; J1[2] = J0[1];
+  const double r00 = r0 * r0, r11 = r1 * r1;
+  const double E1 = 2 * p * (1 - e) / s;
+  D0[0] = ((r11 + r00 * e) * T + E1) / (s * (r1 + r0 * e));
+  D1[0] = T - D0[0];
+  D1[3] = ((r00 + r11 * e) * T + E1) / (s * (r0 + r1 * e));
+  D0[3] = T - D1[3];
+  const double E2 = (p - r00) * (1 - e) / s;
+  D1[1] = ((r00 - p * e) * T + E2) / (s * (r0 - r0 * e));
+  D0[1] = T - D1[1];
+  const double E3 = (p - r11) * (1 - e) / s;
+  D0[2] = ((r11 - p * e) * T + E3) / (s * (r1 - r1 * e));
+  D1[2] = T - D0[2];
+}
+
+/* one site's contribution to the conditional means: downward_process + weighted_J_D_branch
+ * + joint_post (IndepSite.cpp:98-175); adds into J/D [(b-1)*2 + state] */
+static void indep_site_expectation(const orc_state *st, const double *rates, size_t site,
+                                   double *J, double *D, double *w /* 5*n_nodes scratch */) {
+  const int N = st->n_nodes;
+  double *q0 = w, *q1 = w + N, *p0 = w + 2 * N, *p1 = w + 3 * N, *pm = w + 4 * N;
+  indep_upward(st, rates, site, q0, q1, p0, p1);
+  const double pi_0 = rates[1] / (rates[0] + rates[1]);
+  const double a = pi_0 * q0[0], b = (1 - pi_0) * q1[0];
+  pm[0] = a / (a + b);
+  for (int node = 1; node < N; ++node) {
+    const double T = st->blen[node];
+    double P[4], pj[4], J0[4], J1[4], D0[4], D1[4];
+    trans_prob_mat(st, rates[0], rates[1], T, P);
+    const double p0u = pm[st->parent[node]];
+    pj[0] = P[0] * q0[node] * p0u / p0[node];
+    pj[1] = P[1] * q1[node] * p0u / p0[node];
+    pj[2] = P[2] * q0[node] * (1 - p0u) / p1[node];
+    pj[3] = P[3] * q1[node] * (1 - p0u) / p1[node];
+    const double Z = pj[0] + pj[1] + pj[2] + pj[3];
+    for (int i = 0; i < 4; ++i) pj[i] /= Z;
+    pm[node] = pj[0] + pj[2];
+    expectation_JD(st, rates[0], rates[1], T, J0, J1, D0, D1);
+    for (int i = 0; i < 4; ++i) {
+      J[(node - 1) * 2 + 0] += pj[i] * J0[i];
+      J[(node - 1) * 2 + 1] += pj[i] * J1[i];
+      D[(node - 1) * 2 + 0] += pj[i] * D0[i];
+      D[(node - 1) * 2 + 1] += pj[i] * D1[i];
+    }
+  }
+}
+
+static void indep_tree(const orc_state *st, const double *rates, size_t lo, size_t size, double *out,
+                       double *w, int what);
+
+/* expectation_sufficient_statistics (IndepSite.cpp:222-238): sums over ALL sites,
+ * sequentially (reduce_mode SEQ, as the reference) or in the canonical tree order */
+ORC_API void orc_indep_expectation(const orc_state *st, const double *rates, double *J, double *D) {
+  const int B = st->n_nodes - 1;
+  double *w = (double *)malloc(sizeof(double) * 5 * (size_t)st->n_nodes);
+  for (int i = 0; i < 2 * B; ++i) { J[i] = 0.0; D[i] = 0.0; }
+  if (st->reduce_mode == ORC_REDUCE_SEQ) {
+    for (size_t s = 0; s < st->n_sites; ++s) indep_site_expectation(st, rates, s, J, D, w);
+  } else {
+    size_t pad = 1;
+    while (pad < st->n_sites) pad *= 2;
+    double *out = (double *)malloc(sizeof(double) * 4 * (size_t)B);
+    indep_tree(st, rates, 0, pad, out, w, 0);
+    memcpy(J, out, sizeof(double) * 2 * (size_t)B);
+    memcpy(D, out + 2 * B, sizeof(double) * 2 * (size_t)B);
+    free(out);
+  }
+  free(w);
+}
+
+/* per-site J/D of the CURRENT path on every branch (compute_sufficient_statistics,
+ * IndepSite.cpp:266-297); adds into J/D [(b-1)*2 + state] */
+static void indep_site_counts(const orc_state *st, size_t site, double *J, double *D) {
+  for (int b = 1; b < st->n_nodes; ++b) {
+    const orc_path *p = PATH(st, b, site);
+    int prev = p->init;
+    double time = 0.0;
+    for (uint32_t j = 0; j < p->n; ++j) {
+      J[(b - 1) * 2 + prev] += 1;
+      D[(b - 1) * 2 + prev] += (p->t[j] - time);
+      prev = 1 - prev;
+      time = p->t[j];
+    }
+    D[(b - 1) * 2 + prev] += (st->blen[b] - time);
+  }
+}
+
+/* what: 0 = conditional expectations, 1 = counts of the current paths; out = [J | D] */
+static void indep_tree(const orc_state *st, const double *rates, size_t lo, size_t size, double *out,
+                       double *w, int what) {
+  const int B = st->n_nodes - 1;
+  for (int i = 0; i < 4 * B; ++i) out[i] = 0.0;
+  if (lo >= st->n_sites) return;
+  if (size == 1) {
+    if (what == 0) indep_site_expectation(st, rates, lo, out, out + 2 * B, w);
+    else indep_site_counts(st, lo, out, out + 2 * B);
+    return;
+  }
+  double *L = (double *)malloc(sizeof(double) * 8 * (size_t)B), *R = L + 4 * B;
+  indep_tree(st, rates, lo, size / 2, L, w, what);
+  indep_tree(st, rates, lo + size / 2, size / 2, R, w, what);
+  for (int i = 0; i < 4 * B; ++i) out[i] = L[i] + R[i];
+  free(L);
+}
+
+/* compute_sufficient_statistics: per-branch AVERAGES over the sites */
+ORC_API void orc_indep_suffstats(const orc_state *st, double *J, double *D) {
+  const int B = st->n_nodes - 1;
+  for (int i = 0; i < 2 * B; ++i) { J[i] = 0.0; D[i] = 0.0; }
+  if (st->reduce_mode == ORC_REDUCE_SEQ) {
+    /* the reference sums one branch at a time over all sites */
+    for (size_t s = 0; s < st->n_sites; ++s) indep_site_counts(st, s, J, D);
+  } else {
+    size_t pad = 1;
+    while (pad < st->n_sites) pad *= 2;
+    double *out = (double *)malloc(sizeof(double) * 4 * (size_t)B);
+    indep_tree(st, NULL, 0, pad, out, NULL, 1);
+    memcpy(J, out, sizeof(double) * 2 * (size_t)B);
+    memcpy(D, out + 2 * B, sizeof(double) * 2 * (size_t)B);
+    free(out);
+  }
+  for (int i = 0; i < 2 * B; ++i) { J[i] /= (double)st->n_sites; D[i] /= (double)st->n_sites; }
+}
+
+/* update_paths_indep (IndepSite.cpp:241-259) = upward_process + sampling_downward
+ * (:177-215) for every site 0..n-1: the root state is kept, every branch gets a fresh
+ * end state and an end-conditioned path by forward rejection. */
+ORC_API void orc_indep_update_paths(orc_state *st, const double *rates, uint32_t sweep) {
+  const int N = st->n_nodes;
+  double *w = (double *)malloc(sizeof(double) * 4 * (size_t)N);
+  double *q0 = w, *q1 = w + N, *p0 = w + 2 * N, *p1 = w + 3 * N;
+  orc_scratch *sc = &st->scr;
+  for (size_t site = 0; site < st->n_sites; ++site) {
+    indep_upward(st, rates, site, q0, q1, p0, p1);
+    orc_rng g;
+    g.st = st; g.site = (uint32_t)(st->g0 + site); g.sweep = sweep;
+    sc->prop[0].init = PATH(st, 1, site)->init;
+    sc->prop[0].n = 0;
+    for (int node = 1; node < N; ++node) {
+      orc_path *pp = &sc->prop[node];
+      const int start = path_end_state(&sc->prop[st->parent[node]]);
+      pp->init = (uint8_t)start;
+      pp->n = 0;
+      double P[4];
+      trans_prob_mat(st, rates[0], rates[1], st->blen[node], P);
+      const double pr0 = P[2 * start] * q0[node] / (start ? p1[node] : p0[node]);
+      const double u = rng_segment_uniform(&g, (uint32_t)node, 0);
+      const int sampled = (u > pr0);
+      forward_rejection(st, sc, &g, (uint32_t)node, 0, rates[0], rates[1], start, sampled,
+                        st->blen[node], 0.0, pp);
+    }
+    for (int node = 1; node < N; ++node) {
+      orc_path *dst = PATH(st, node, site), *src = &sc->prop[node];
+      orc_path tmp = *dst; *dst = *src; *src = tmp;
+    }
+  }
+  free(w);
+}
+
 /* ------------------------------------------------ initial paths for one branch
  * initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110): every site gets an
  * end-conditioned path root[i] -> leaf[i] on [0,T] drawn independently by forward

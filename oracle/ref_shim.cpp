@@ -27,6 +27,7 @@
 #include "SingleSiteSampler.hpp"
 #include "ParamEstimation.hpp"
 #include "EndCondSampling.hpp"
+#include "IndepSite.hpp"
 
 using std::vector;
 using std::array;
@@ -254,6 +255,43 @@ uint64_t ref_init_paths_indep(uint64_t seed, const double *rates, uint64_t n, co
   }
   offsets[n] = tot;
   return tot;
+}
+
+/* ---- site-independent model: the linked IndepSite.cpp */
+void ref_indep_expectation(void *h, const double *rates, double *J, double *D) {
+  RefState *st = static_cast<RefState *>(h);
+  vector<double> r(rates, rates + 2);
+  vector<vector<double> > Jv, Dv;
+  expectation_sufficient_statistics(r, st->th, st->paths, Jv, Dv);
+  for (size_t b = 1; b < st->th.n_nodes; ++b)
+    for (size_t i = 0; i < 2; ++i) { J[(b - 1) * 2 + i] = Jv[b][i]; D[(b - 1) * 2 + i] = Dv[b][i]; }
+}
+void ref_indep_suffstats(void *h, double *J, double *D) {
+  RefState *st = static_cast<RefState *>(h);
+  vector<vector<double> > Jv, Dv;
+  compute_sufficient_statistics(st->paths, Jv, Dv);
+  for (size_t b = 1; b < st->th.n_nodes; ++b)
+    for (size_t i = 0; i < 2; ++i) { J[(b - 1) * 2 + i] = Jv[b][i]; D[(b - 1) * 2 + i] = Dv[b][i]; }
+}
+void ref_indep_update_paths(void *h, const double *rates) {
+  RefState *st = static_cast<RefState *>(h);
+  vector<double> r(rates, rates + 2);
+  update_paths_indep(r, st->th, st->paths, st->gen);
+}
+/* M-steps of the site-independent model (IndepSite.cpp:299-360); J/D [(b-1)*2+i];
+ * rates, branches in/out; with optimize != 0 the resident paths are rescaled too */
+void ref_indep_m_step(void *h, int optimize, const double *J, const double *D, double *rates,
+                      double *branches) {
+  RefState *st = static_cast<RefState *>(h);
+  const size_t N = st->th.n_nodes;
+  vector<vector<double> > Jv(N, vector<double>(2, 0.0)), Dv(N, vector<double>(2, 0.0));
+  for (size_t b = 1; b < N; ++b)
+    for (size_t i = 0; i < 2; ++i) { Jv[b][i] = J[(b - 1) * 2 + i]; Dv[b][i] = D[(b - 1) * 2 + i]; }
+  vector<double> r(rates, rates + 2);
+  if (!optimize) estimate_rates_indep(Jv, Dv, r, st->th);
+  else estimate_rates_and_branches_indep(Jv, Dv, r, st->th, st->paths);
+  rates[0] = r[0]; rates[1] = r[1];
+  for (size_t b = 0; b < N; ++b) branches[b] = st->th.branches[b];
 }
 
 /* ---- per-function known answers */

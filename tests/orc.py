@@ -73,6 +73,9 @@ def orc_lib():
         L.orc_kat_end_cond_means.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_uint64, dp]
         L.orc_init_paths_indep.argtypes = [C.c_int, C.c_int, C.c_uint64, dp, C.c_uint64, u8p, u8p, C.c_double, u8p, u64p, dp, C.c_uint64]
         L.orc_init_paths_indep.restype = C.c_uint64
+        L.orc_indep_expectation.argtypes = [C.c_void_p, dp, dp, dp]
+        L.orc_indep_suffstats.argtypes = [C.c_void_p, dp, dp]
+        L.orc_indep_update_paths.argtypes = [C.c_void_p, dp, C.c_uint32]
         L.orc_kat_exp.argtypes = [C.c_double]
         L.orc_kat_exp.restype = C.c_double
         L.orc_kat_log.argtypes = [C.c_double]
@@ -121,6 +124,11 @@ def ref_lib():
                                         C.c_uint32, dp, C.c_double, dp, dp]
         L.ref_kat_expectations.argtypes = [C.c_double, C.c_double, C.c_double, dp]
         L.ref_kat_mt_canonical.argtypes = [C.c_uint64, C.c_uint64, dp]
+        if hasattr(L, 'ref_indep_expectation'):
+            L.ref_indep_expectation.argtypes = [C.c_void_p, dp, dp, dp]
+            L.ref_indep_suffstats.argtypes = [C.c_void_p, dp, dp]
+            L.ref_indep_update_paths.argtypes = [C.c_void_p, dp]
+            L.ref_indep_m_step.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp]
         if hasattr(L, 'ref_init_paths_indep'):
             L.ref_init_paths_indep.argtypes = [C.c_uint64, dp, C.c_uint64, u8p, u8p, C.c_double, u8p, u64p, dp, C.c_uint64]
             L.ref_init_paths_indep.restype = C.c_uint64
@@ -175,6 +183,21 @@ class _Engine:
         return FlatPaths(self.n_sites, self.n_nodes, init, off, jumps[:tot])
 
 
+def _indep_methods(cls, px):
+    def indep_expectation(self, rates):
+        r = np.ascontiguousarray(rates, np.float64)
+        J, D = np.zeros(self.B * 2), np.zeros(self.B * 2)
+        getattr(self.L, px + "_indep_expectation")(self.h, _p(r, C.c_double), _p(J, C.c_double), _p(D, C.c_double))
+        return J, D
+
+    def indep_suffstats(self):
+        J, D = np.zeros(self.B * 2), np.zeros(self.B * 2)
+        getattr(self.L, px + "_indep_suffstats")(self.h, _p(J, C.c_double), _p(D, C.c_double))
+        return J, D
+    cls.indep_expectation, cls.indep_suffstats = indep_expectation, indep_suffstats
+    return cls
+
+
 class Oracle(_Engine):
     def __init__(self, tree, model, fp, rung="A", cap=0, seed=0):
         super().__init__(orc_lib(), "orc", tree, model, fp)
@@ -215,6 +238,10 @@ class Oracle(_Engine):
                             _p(D, C.c_double), C.byref(nacc), C.byref(acc))
         return J, D, int(nacc.value), acc.value
 
+    def indep_update_paths(self, rates, sweep=0):
+        r = np.ascontiguousarray(rates, np.float64)
+        self.L.orc_indep_update_paths(self.h, _p(r, C.c_double), sweep)
+
     def counters(self):
         out = np.zeros(4, np.uint64)
         self.L.orc_get_counters(self.h, _p(out, C.c_uint64))
@@ -248,6 +275,29 @@ class Reference(_Engine):
         acc = C.c_double(0)
         self.L.ref_run_mcmc(self.h, _p(J, C.c_double), _p(D, C.c_double), C.byref(acc))
         return J, D, acc.value
+
+
+_indep_methods(Oracle, "orc")
+_indep_methods(Reference, "ref")
+
+
+def _ref_indep_update(self, rates):
+    r = np.ascontiguousarray(rates, np.float64)
+    self.L.ref_indep_update_paths(self.h, _p(r, C.c_double))
+
+
+def _ref_indep_m_step(self, optimize, J, D, rates, n_nodes):
+    r = np.ascontiguousarray(rates, np.float64).copy()
+    br = np.zeros(n_nodes)
+    J = np.ascontiguousarray(J, np.float64)
+    D = np.ascontiguousarray(D, np.float64)
+    self.L.ref_indep_m_step(self.h, int(optimize), _p(J, C.c_double), _p(D, C.c_double),
+                            _p(r, C.c_double), _p(br, C.c_double))
+    return r, br
+
+
+Reference.indep_update_paths = _ref_indep_update
+Reference.indep_m_step = _ref_indep_m_step
 
 
 def paths_equal(a, b):
