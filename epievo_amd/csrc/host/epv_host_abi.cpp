@@ -8,6 +8,7 @@
 #include "epv_model.hpp"
 #include "epv_sim.hpp"
 #include "epv_io.hpp"
+#include "epv_indep.hpp"
 
 namespace {
 thread_local std::string g_err;
@@ -142,4 +143,44 @@ EPVH_API int epvh_read_tree(const char *tree_file, int max_nodes, uint32_t *subt
     put_text(joined, names_buf, names_len);
     return n;
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// ---- site-independent stage of epievo_initialization (host parts)
+EPVH_API int epvh_indep_m_step(int optimize_branches, int n_nodes, const double *J, const double *D,
+                               double *rates, double *branches) {
+  try {
+    if (!optimize_branches) {
+      epv::estimate_rates_indep(n_nodes, J, D, rates);
+    } else {
+      std::vector<double> br(branches, branches + n_nodes);
+      epv::estimate_rates_and_branches_indep(n_nodes, J, D, rates, br);
+      for (int b = 0; b < n_nodes; ++b) branches[b] = br[b];
+    }
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+EPVH_API int epvh_model_from_indep_rates(const double *rates2, double *rates, double *T, double *baseline) {
+  try {
+    put_model(epv::model_from_indep_rates(rates2), rates, T, baseline);
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// states: [n_nodes][n_sites] row-major, updated in place with the drawn internal states
+EPVH_API void *epvh_initialize_paths_heuristic(uint64_t seed, int n_nodes, const uint32_t *subtree,
+                                               const uint32_t *parent, const double *branches,
+                                               uint64_t n_sites, uint8_t *states) {
+  try {
+    epv::Tree t;
+    t.subtree_sizes.assign(subtree, subtree + n_nodes);
+    t.parent_ids.assign(parent, parent + n_nodes);
+    t.branches.assign(branches, branches + n_nodes);
+    t.node_names.assign(n_nodes, "");
+    std::vector<std::vector<uint8_t>> st(n_nodes);
+    for (int b = 0; b < n_nodes; ++b) st[b].assign(states + (uint64_t)b * n_sites, states + (uint64_t)(b + 1) * n_sites);
+    epv::FlatPaths *fp = new epv::FlatPaths(epv::initialize_paths_heuristic(seed, t, st));
+    for (int b = 0; b < n_nodes; ++b) std::memcpy(states + (uint64_t)b * n_sites, st[b].data(), n_sites);
+    return fp;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }

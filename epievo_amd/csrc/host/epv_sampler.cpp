@@ -77,6 +77,50 @@ void SingleSiteSampler::scale_jump_times(const std::vector<double> &new_branches
   check(epv_scale_jump_times(ctx_, new_branches.data()), "epv_scale_jump_times");
 }
 
+void SingleSiteSampler::upload(const Tree &th, const FlatPaths &paths) {
+  n_nodes_ = th.n_nodes();
+  n_sites_ = paths.n_sites;
+  check(epv_set_tree(ctx_, th.n_nodes(), th.parent_ids.data(), th.subtree_sizes.data(),
+                     th.branches.data()), "epv_set_tree");
+  // the kernels of the site-independent stage never read the 8 rates; park neutral ones
+  const double ones[8] = {1, 1, 1, 1, 1, 1, 1, 1}, T[4] = {0.5, 0.5, 0.5, 0.5};
+  check(epv_set_model(ctx_, ones, T), "epv_set_model");
+  const double dummy = 0.0;
+  check(epv_upload_paths(ctx_, paths.n_sites, paths.init.data(), paths.offsets.data(),
+                         paths.jumps.empty() ? &dummy : paths.jumps.data(), capacity_, 0),
+        "epv_upload_paths");
+}
+
+void SingleSiteSampler::get_sufficient_statistics(std::vector<std::vector<double>> &J,
+                                                  std::vector<std::vector<double>> &D) {
+  const size_t B = (size_t)n_nodes_ - 1;
+  std::vector<double> Jf(B * 8), Df(B * 8);
+  check(epv_get_sufficient_statistics(ctx_, Jf.data(), Df.data()), "epv_get_sufficient_statistics");
+  J.assign(n_nodes_, {});
+  D.assign(n_nodes_, {});
+  for (size_t b = 1; b <= B; ++b) {
+    J[b].assign(Jf.begin() + (b - 1) * 8, Jf.begin() + b * 8);
+    D[b].assign(Df.begin() + (b - 1) * 8, Df.begin() + b * 8);
+  }
+}
+
+void SingleSiteSampler::indep_expectation(const double rates[2], std::vector<double> &J,
+                                          std::vector<double> &D) {
+  J.assign(((size_t)n_nodes_ - 1) * 2, 0.0);
+  D.assign(((size_t)n_nodes_ - 1) * 2, 0.0);
+  check(epv_indep_expectation(ctx_, rates, J.data(), D.data()), "epv_indep_expectation");
+}
+
+void SingleSiteSampler::indep_sufficient_statistics(std::vector<double> &J, std::vector<double> &D) {
+  J.assign(((size_t)n_nodes_ - 1) * 2, 0.0);
+  D.assign(((size_t)n_nodes_ - 1) * 2, 0.0);
+  check(epv_indep_sufficient_statistics(ctx_, J.data(), D.data()), "epv_indep_sufficient_statistics");
+}
+
+void SingleSiteSampler::indep_update_paths(const double rates[2], uint64_t seed, uint32_t sweep) {
+  check(epv_indep_update_paths(ctx_, rates, seed, sweep), "epv_indep_update_paths");
+}
+
 void SingleSiteSampler::download(FlatPaths &paths) {
   uint64_t total = 0;
   check(epv_paths_total_jumps(ctx_, &total), "epv_paths_total_jumps");

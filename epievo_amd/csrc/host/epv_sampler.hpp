@@ -55,6 +55,16 @@ public:
 
   void download(FlatPaths &paths);
 
+  // upload paths without touching the model (the site-independent stage has no EpiEvoModel yet)
+  void upload(const Tree &th, const FlatPaths &paths);
+  // get_sufficient_statistics, per-branch overload (ParamEstimation.cpp:92-114), of the
+  // resident paths: rows 1..n_nodes-1 of 8 contexts
+  void get_sufficient_statistics(std::vector<std::vector<double>> &J, std::vector<std::vector<double>> &D);
+  // the site-independent model of IndepSite.hpp:40-72; J/D flat [(b-1)*2 + state]
+  void indep_expectation(const double rates[2], std::vector<double> &J, std::vector<double> &D);
+  void indep_sufficient_statistics(std::vector<double> &J, std::vector<double> &D);
+  void indep_update_paths(const double rates[2], uint64_t seed, uint32_t sweep);
+
   // MCMC parameter constants (public fields of the reference class)
   bool SAMPLE_ROOT;  // hard-wired false in the reference (SingleSiteSampler.cpp:441)
   size_t burn_in;

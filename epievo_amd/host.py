@@ -37,6 +37,10 @@ def lib():
         L.epvh_read_paths.restype = C.c_void_p
         L.epvh_write_paths.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint64, dp, u8p, u64p, dp]
         L.epvh_read_tree.argtypes = [C.c_char_p, C.c_int, u32p, u32p, dp, C.c_char_p, C.c_int]
+        L.epvh_indep_m_step.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp]
+        L.epvh_model_from_indep_rates.argtypes = [dp, dp, dp, dp]
+        L.epvh_initialize_paths_heuristic.argtypes = [C.c_uint64, C.c_int, u32p, u32p, dp, C.c_uint64, u8p]
+        L.epvh_initialize_paths_heuristic.restype = C.c_void_p
         _lib = L
     return _lib
 
@@ -183,3 +187,37 @@ def m_step(model, tree_branches, J, D, optimize_branches=False):
                          _p(br, C.c_double), C.byref(llh), buf, len(buf)):
         raise RuntimeError(lib().epvh_last_error().decode())
     return Model(rates, T, bl), br, llh.value, buf.value.decode()
+
+
+def indep_m_step(rates, branches, J, D, optimize_branches=False):
+    """M-step of the site-independent model (IndepSite.cpp:299-360) -> (rates[2], branches)"""
+    r = np.ascontiguousarray(rates, np.float64).copy()
+    br = np.ascontiguousarray(branches, np.float64).copy()
+    J = np.ascontiguousarray(J, np.float64)
+    D = np.ascontiguousarray(D, np.float64)
+    if lib().epvh_indep_m_step(int(optimize_branches), len(br), _p(J, C.c_double), _p(D, C.c_double),
+                               _p(r, C.c_double), _p(br, C.c_double)):
+        raise RuntimeError(lib().epvh_last_error().decode())
+    return r, br
+
+
+def model_from_indep_rates(rates2):
+    r2 = np.ascontiguousarray(rates2, np.float64)
+    rates, T, bl = np.zeros(8), np.zeros(4), np.zeros(4)
+    if lib().epvh_model_from_indep_rates(_p(r2, C.c_double), _p(rates, C.c_double), _p(T, C.c_double),
+                                         _p(bl, C.c_double)):
+        raise RuntimeError(lib().epvh_last_error().decode())
+    return Model(rates, T, bl)
+
+
+def initialize_paths_heuristic(seed, tree, states):
+    """epievo_initialization's heuristic start; states [n_nodes][n_sites] uint8 (leaves filled,
+    internal nodes overwritten) -> FlatPaths"""
+    st = np.ascontiguousarray(states, np.uint8)
+    h = lib().epvh_initialize_paths_heuristic(int(seed), tree.n_nodes, _p(tree.subtree_sizes, C.c_uint32),
+                                              _p(tree.parent_ids, C.c_uint32), _p(tree.branches, C.c_double),
+                                              st.shape[1], _p(st, C.c_uint8))
+    if not h:
+        raise RuntimeError(lib().epvh_last_error().decode())
+    states[...] = st
+    return FlatPaths._from_handle(h)

@@ -87,3 +87,57 @@ def test_sim_pairwise_runs_and_keeps_end_states(tmp_path):
     r = subprocess.run([os.path.join(BIN, "epievo_sim_pairwise"), d + "/p.param", d + "/obs.states"],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "required" in r.stderr
+
+
+@pytest.mark.parametrize("optimize", [False, True])
+def test_initialization_matches_oracle_pipeline(tmp_path, optimize):
+    """epievo_initialization end to end (states at the leaves -> initial param + local_paths)
+    against the same pipeline driven through the CPU oracle's parallel rung"""
+    model, tree, fp = simulate("tree", 4000, seed=31)
+    d = str(tmp_path)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+    B, n, N = tree.n_nodes - 1, fp.n_sites, tree.n_nodes
+    es = fp.init.reshape(B, n) ^ (fp.counts().reshape(B, n) & 1).astype(np.uint8)
+    leaves = [i for i in range(N) if tree.subtree_sizes[i] == 1]
+    with open(d + "/obs.states", "w") as f:
+        f.write("#" + "\t".join(tree.node_names[i] for i in leaves) + "\n")
+        for s in range(n):
+            f.write("%d\t%s\n" % (s, "\t".join(str(es[i - 1, s]) for i in leaves)))
+    cmd = [os.path.join(BIN, "epievo_initialization"), "-i", "4", "-B", "3", "-s", "5", "-p", d + "/out.param",
+           "-o", d + "/out.paths", "-t", d + "/out.nwk", "-v"]
+    if optimize:
+        cmd.append("-b")
+    r = subprocess.run(cmd + [d + "/t.nwk", d + "/obs.states"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+    # the same pipeline: host heuristics + host M-steps + oracle rung B for the O(n) parts
+    st = np.zeros((N, n), np.uint8)
+    st[leaves] = es[[i - 1 for i in leaves]]
+    p0 = host.initialize_paths_heuristic(5, tree, st)
+    dummy = host.Model(np.ones(8), np.full(4, 0.5), np.zeros(4))
+    o = orc.Oracle(tree, dummy, p0, "B", cap=32, seed=5)
+    rates, br = np.zeros(2), tree.branches.copy()
+    J, D = o.indep_suffstats()
+    for it in range(4):
+        rates, br_new = host.indep_m_step(rates, br, J, D, optimize_branches=optimize)
+        if optimize:
+            o.scale_jump_times(br_new)
+            br = br_new
+        J, D = o.indep_expectation(rates)
+    Jt, Dt = np.zeros(B * 8), np.zeros(B * 8)
+    for i in range(3):
+        o.indep_update_paths(rates, 0xF0000000 + i)
+        J1, D1 = o.suffstats()
+        Jt += J1
+        Dt += D1
+    Jt /= 3
+    Dt /= 3
+    m2, br2, llh, text = host.m_step(host.model_from_indep_rates(rates), br, Jt, Dt, optimize_branches=optimize)
+    o.scale_jump_times(br2)
+    assert open(d + "/out.param").read() == text + "\n"
+    host.write_paths(d + "/exp.paths", tree.node_names, br2, o.paths())
+    assert open(d + "/out.paths", "rb").read() == open(d + "/exp.paths", "rb").read()
+    # the fitted model is sane: positive rates, leaves kept
+    out, names, tt = host.read_paths(d + "/out.paths")
+    es2 = out.init.reshape(B, n) ^ (out.counts().reshape(B, n) & 1).astype(np.uint8)
+    assert np.array_equal(es2[[i - 1 for i in leaves]], es[[i - 1 for i in leaves]])
