@@ -28,12 +28,24 @@ def _oracle_em(model, tree, fp, iters, burn, batch, seed, optimize):
     return model, branches, text, o.paths()
 
 
-@pytest.mark.parametrize("optimize", [False, True])
-def test_est_params_histories_matches_oracle_em(tmp_path, optimize):
-    model, tree, fp = simulate("tree", 3000, seed=21)
+def _newick(tree):
+    """Newick text of a pre-order array tree (all nodes named)"""
+    def rec(i):
+        kids, c = [], 1
+        while c < tree.subtree_sizes[i]:
+            kids.append(rec(i + c))
+            c += tree.subtree_sizes[i + c]
+        return ("(" + ",".join(kids) + ")" if kids else "") + "%s:%.17g" % (tree.node_names[i], tree.branches[i])
+    return rec(0) + ";\n"
+
+
+@pytest.mark.parametrize("cfg,optimize", [("tree", False), ("tree", True), ("bal16", True)])
+def test_est_params_histories_matches_oracle_em(tmp_path, cfg, optimize):
+    """BASELINE configs 3 and 5 in miniature (tree.nwk; a balanced 16-leaf tree with -b)"""
+    model, tree, fp = simulate(cfg, 3000 if cfg == "tree" else 800, seed=21)
     d = str(tmp_path)
     open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
-    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT if cfg == "tree" else _newick(tree))
     host.write_paths(d + "/in.paths", tree.node_names, tree.branches, fp)
     cmd = [os.path.join(BIN, "epievo_est_params_histories"), "-i", "2", "-B", "3", "-L", "2", "-s", "77",
            "-o", d + "/out.paths", "-p", d + "/out.param", "-t", d + "/out.nwk", "-v"]
