@@ -22,7 +22,7 @@ HIP_SO = os.path.join(PKG, "libepievo_mi355x.so")
 HOST_SO = os.path.join(PKG, "libepv_host.so")
 BIN_DIR = os.path.join(PKG, "bin")
 
-HOST_SOURCES = ["epv_model.cpp", "epv_sim.cpp", "epv_io.cpp", "epv_indep.cpp", "epv_host_abi.cpp"]
+HOST_SOURCES = ["epv_model.cpp", "epv_sim.cpp", "epv_io.cpp", "epv_indep.cpp", "epv_forward.cpp", "epv_host_abi.cpp"]
 # the reference library is built -O3 without -march (no FMA contraction); match it
 HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall"]
 
@@ -94,7 +94,7 @@ def build_cli(force=False):
     cli = os.path.join(HOST, "cli")
     os.makedirs(BIN_DIR, exist_ok=True)
     common = [os.path.join(HOST, f) for f in ("epv_model.cpp", "epv_sim.cpp", "epv_io.cpp", "epv_indep.cpp",
-                                              "epv_sampler.cpp", "epv_options.cpp")]
+                                              "epv_forward.cpp", "epv_sampler.cpp", "epv_options.cpp")]
     outs = []
     for f in sorted(os.listdir(cli)):
         if not f.endswith(".cpp"):

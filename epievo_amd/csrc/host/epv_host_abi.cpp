@@ -9,6 +9,7 @@
 #include "epv_sim.hpp"
 #include "epv_io.hpp"
 #include "epv_indep.hpp"
+#include "epv_forward.hpp"
 
 namespace {
 thread_local std::string g_err;
@@ -183,4 +184,37 @@ EPVH_API void *epvh_initialize_paths_heuristic(uint64_t seed, int n_nodes, const
     for (int b = 0; b < n_nodes; ++b) std::memcpy(states + (uint64_t)b * n_sites, st[b].data(), n_sites);
     return fp;
   } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+
+// ---- forward simulation (epievo_sim): same outputs as the test shim's ref_forward_sim
+EPVH_API uint64_t epvh_forward_sim(uint64_t seed, const double *rates, const double *T, int n_nodes,
+                                   const uint32_t *parent, const double *branches, uint64_t n_sites,
+                                   uint8_t *sequences, uint64_t *jump_offsets, double *jump_times,
+                                   uint64_t *jump_positions, uint64_t cap) {
+  epv::Model m;
+  for (int i = 0; i < 8; ++i) m.rates[i] = rates[i];
+  for (int i = 0; i < 4; ++i) m.T[i] = T[i];
+  epv::Tree th;
+  th.parent_ids.assign(parent, parent + n_nodes);
+  th.branches.assign(branches, branches + n_nodes);
+  th.subtree_sizes.assign(n_nodes, 1);   // only n_nodes() is needed here
+  th.node_names.assign(n_nodes, "");
+  std::mt19937 gen(seed);
+  std::vector<uint8_t> root;
+  epv::sample_root(m, n_sites, gen, root);
+  std::vector<std::vector<uint8_t>> seqs;
+  std::vector<std::vector<epv::GlobalJump>> paths;
+  std::vector<size_t> events;
+  epv::simulate_tree(m, th, root, gen, seqs, paths, events);
+  uint64_t tot = 0;
+  jump_offsets[0] = 0;
+  for (int node = 0; node < n_nodes; ++node) {
+    for (const epv::GlobalJump &j : paths[node]) {
+      if (tot < cap) { jump_times[tot] = j.timepoint; jump_positions[tot] = j.position; }
+      ++tot;
+    }
+    jump_offsets[node + 1] = tot;
+    std::memcpy(sequences + (uint64_t)node * n_sites, seqs[node].data(), n_sites);
+  }
+  return tot;
 }

@@ -18,6 +18,8 @@
 #include <sstream>
 #include <cstring>
 #include <cstdint>
+#include <numeric>
+#include <algorithm>
 
 #include "Path.hpp"
 #include "Segment.hpp"
@@ -28,6 +30,8 @@
 #include "ParamEstimation.hpp"
 #include "EndCondSampling.hpp"
 #include "IndepSite.hpp"
+#include "TripletSampler.hpp"
+#include "GlobalJump.hpp"
 
 using std::vector;
 using std::array;
@@ -292,6 +296,52 @@ void ref_indep_m_step(void *h, int optimize, const double *J, const double *D, d
   else estimate_rates_and_branches_indep(Jv, Dv, r, st->th, st->paths);
   rates[0] = r[0]; rates[1] = r[1];
   for (size_t b = 0; b < N; ++b) branches[b] = st->th.branches[b];
+}
+
+/* ---- forward simulation: the glue of epievo_sim's main (src/prog/epievo_sim.cpp:102-152,
+ * 288-352) around the LINKED TripletSampler and EpiEvoModel::sample_state_sequence.
+ * Outputs: sequences [n_nodes][n_sites]; global jumps of all nodes concatenated with
+ * jump_offsets[n_nodes+1]; returns the number of jumps (or what is needed if > cap). */
+uint64_t ref_forward_sim(uint64_t seed, const double *rates, const double *T, int n_nodes,
+                         const uint32_t *parent, const double *branches, uint64_t n_sites,
+                         uint8_t *sequences, uint64_t *jump_offsets, double *jump_times,
+                         uint64_t *jump_positions, uint64_t cap) {
+  EpiEvoModel m;
+  set_model(m, rates, T);
+  std::mt19937 gen(seed);
+  state_seq root;
+  m.sample_state_sequence(n_sites, gen, root);
+  vector<state_seq> seqs(n_nodes, root);
+  uint64_t tot = 0;
+  jump_offsets[0] = 0;
+  jump_offsets[1] = 0;
+  for (int node = 1; node < n_nodes; ++node) {
+    TripletSampler ts(seqs[parent[node]]);
+    double time_value = 0;
+    while (time_value < branches[node]) {
+      vector<size_t> counts;
+      ts.get_triplet_counts(counts);
+      const double holding_rate =
+          std::inner_product(counts.begin(), counts.end(), m.triplet_rates.begin(), 0.0);
+      std::exponential_distribution<double> exp_distr(holding_rate);
+      const double holding_time = std::max(exp_distr(gen), std::numeric_limits<double>::min());
+      time_value += holding_time;
+      if (time_value < branches[node]) {
+        vector<double> prob(8, 0.0);
+        for (size_t i = 0; i < 8; ++i) prob[i] = counts[i] * m.triplet_rates[i] / holding_rate;
+        std::discrete_distribution<size_t> multinom(prob.begin(), prob.end());
+        const size_t context = multinom(gen);
+        const size_t pos = ts.random_mutate(context, gen);
+        if (tot < cap) { jump_times[tot] = time_value; jump_positions[tot] = pos; }
+        ++tot;
+      }
+    }
+    ts.get_sequence(seqs[node]);
+    jump_offsets[node + 1] = tot;
+  }
+  for (int node = 0; node < n_nodes; ++node)
+    for (uint64_t s = 0; s < n_sites; ++s) sequences[(uint64_t)node * n_sites + s] = seqs[node][s];
+  return tot;
 }
 
 /* ---- per-function known answers */

@@ -141,6 +141,21 @@ def kat():
         r, T, bl = np.zeros(8), np.zeros(4), np.zeros(4)
         assert L.ref_read_model(pf, sc, orc._p(r, dbl), orc._p(T, dbl), orc._p(bl, dbl)) == 0
         out["model_%s_rates" % tag], out["model_%s_T" % tag], out["model_%s_bl" % tag] = r, T, bl
+    # forward simulation through the LINKED TripletSampler (ref_forward_sim)
+    from common import config
+    u8p, u32p, u64p, dp = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_double))
+    L.ref_forward_sim.restype = C.c_uint64
+    L.ref_forward_sim.argtypes = [C.c_uint64, dp, dp, C.c_int, u32p, dp, C.c_uint64, u8p, u64p, dp, u64p, C.c_uint64]
+    for cfg, n in (("tree", 600), ("pair", 300)):
+        tree = config(cfg)
+        N, cap = tree.n_nodes, 40 * n
+        seqs, off = np.zeros(N * n, np.uint8), np.zeros(N + 1, np.uint64)
+        tt, pp = np.zeros(cap), np.zeros(cap, np.uint64)
+        tot = L.ref_forward_sim(42, orc._p(model.rates, dbl), orc._p(model.T, dbl), N, orc._p(tree.parent_ids, C.c_uint32),
+                                orc._p(tree.branches, dbl), n, orc._p(seqs, C.c_uint8), orc._p(off, C.c_uint64),
+                                orc._p(tt, dbl), orc._p(pp, C.c_uint64), cap)
+        out["fwd_%s_seqs" % cfg], out["fwd_%s_off" % cfg] = seqs, off
+        out["fwd_%s_t" % cfg], out["fwd_%s_p" % cfg] = tt[:tot], pp[:tot]
     np.savez_compressed(os.path.join(HERE, "kat.npz"), **out)
     print("wrote kat")
 

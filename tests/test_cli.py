@@ -153,3 +153,30 @@ def test_initialization_matches_oracle_pipeline(tmp_path, optimize):
     out, names, tt = host.read_paths(d + "/out.paths")
     es2 = out.init.reshape(B, n) ^ (out.counts().reshape(B, n) & 1).astype(np.uint8)
     assert np.array_equal(es2[[i - 1 for i in leaves]], es[[i - 1 for i in leaves]])
+
+
+@pytest.mark.parametrize("optimize", [False, True])
+def test_est_complete_matches_host_m_step(tmp_path, optimize):
+    """epievo_est_complete: GPU sufficient statistics + host M-step on complete histories"""
+    model, tree, fp = simulate("tree", 5000, seed=12)
+    d = str(tmp_path)
+    open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+    host.write_paths(d + "/in.paths", tree.node_names, tree.branches, fp)
+    cmd = [os.path.join(BIN, "epievo_est_complete"), "-o", d + "/out.param", "-t", d + "/out.nwk"]
+    if optimize:
+        cmd.append("-b")
+    r = subprocess.run(cmd + [d + "/p.param", d + "/t.nwk", d + "/in.paths"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    o = orc.Oracle(tree, model, fp, "B", cap=16)
+    if optimize:
+        o.scale_jump_times(np.concatenate([[0.0], np.ones(tree.n_nodes - 1)]))
+    J, D = o.suffstats()
+    m2, br, llh, text = host.m_step(model, tree.branches, J, D, optimize_branches=optimize)
+    assert open(d + "/out.param").read() == text + "\n"
+    # the estimates are close to the truth the data were simulated from
+    est = host.Model.read(d + "/out.param", scale=True)
+    np.testing.assert_allclose(est.T, model.T, atol=0.03)
+    if optimize:
+        t2 = host.Tree.read(d + "/out.nwk")
+        np.testing.assert_allclose(t2.branches, br, rtol=1e-5)
