@@ -999,6 +999,53 @@ ORC_API uint64_t orc_init_paths_indep(int rng_mode, int math_mode, uint64_t seed
   return tot;
 }
 
+/* ------------------------------------------------ exact posterior by whole-sequence rejection
+ * The reference's own end-to-end check of the sampler (src/harnesses/MCMC_test.cpp:191-216,
+ * 367-379): forward-simulate the whole sequence from the root (Gillespie over the interior
+ * sites, ends fixed) and keep only histories that hit the observed leaf sequence; the kept
+ * histories are exact draws from the posterior the MCMC targets.  Feasible for a handful of
+ * sites only.  Returns the number of kept histories; Jm/Dm = means of the 8-context
+ * sufficient statistics over the interior triples, J2/D2 = means of their squares. */
+ORC_API uint64_t orc_exact_posterior(const double *rates, uint64_t n, const uint8_t *root,
+                                     const uint8_t *leaf, double T, uint64_t seed, uint64_t want,
+                                     uint64_t max_trials, double *Jm, double *Dm, double *J2, double *D2) {
+  orc_mt19937 g;
+  orc_mt_seed(&g, (uint32_t)seed);
+  orc_path *paths = (orc_path *)calloc(n, sizeof(orc_path));
+  uint8_t *seq = (uint8_t *)malloc(n);
+  for (int c = 0; c < 8; ++c) { Jm[c] = Dm[c] = J2[c] = D2[c] = 0.0; }
+  uint64_t kept = 0;
+  for (uint64_t trial = 0; trial < max_trials && kept < want; ++trial) {
+    memcpy(seq, root, n);
+    for (uint64_t s = 0; s < n; ++s) { paths[s].init = root[s]; paths[s].n = 0; }
+    double t = 0.0;
+    for (;;) {
+      double total = 0.0;
+      for (uint64_t s = 1; s + 1 < n; ++s) total += rates[4 * seq[s - 1] + 2 * seq[s] + seq[s + 1]];
+      t += -log(1.0 - orc_mt_canonical(&g)) / total;
+      if (!(t < T)) break;
+      double x = orc_mt_canonical(&g) * total;
+      uint64_t pick = n - 2;
+      for (uint64_t s = 1; s + 1 < n; ++s) {
+        const double r = rates[4 * seq[s - 1] + 2 * seq[s] + seq[s + 1]];
+        if (x < r) { pick = s; break; }
+        x -= r;
+      }
+      seq[pick] ^= 1;
+      path_push(&paths[pick], t);
+    }
+    if (memcmp(seq, leaf, n) != 0) continue;
+    double J[8] = {0, 0, 0, 0, 0, 0, 0, 0}, D[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint64_t s = 1; s + 1 < n; ++s) add_suff_stats(&paths[s - 1], &paths[s], &paths[s + 1], T, J, D);
+    for (int c = 0; c < 8; ++c) { Jm[c] += J[c]; Dm[c] += D[c]; J2[c] += J[c] * J[c]; D2[c] += D[c] * D[c]; }
+    ++kept;
+  }
+  for (int c = 0; c < 8 && kept; ++c) { Jm[c] /= kept; Dm[c] /= kept; J2[c] /= kept; D2[c] /= kept; }
+  for (uint64_t s = 0; s < n; ++s) free(paths[s].t);
+  free(paths); free(seq);
+  return kept;
+}
+
 /* ------------------------------------------------- per-function KAT hooks */
 ORC_API void orc_kat_trans_prob_mat(int math_mode, double r0, double r1, double t, double *P) {
   orc_state st; st.math_mode = math_mode; set_math(&st);

@@ -76,6 +76,8 @@ def orc_lib():
         L.orc_indep_expectation.argtypes = [C.c_void_p, dp, dp, dp]
         L.orc_indep_suffstats.argtypes = [C.c_void_p, dp, dp]
         L.orc_indep_update_paths.argtypes = [C.c_void_p, dp, C.c_uint32]
+        L.orc_exact_posterior.argtypes = [dp, C.c_uint64, u8p, u8p, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, dp, dp, dp, dp]
+        L.orc_exact_posterior.restype = C.c_uint64
         L.orc_kat_exp.argtypes = [C.c_double]
         L.orc_kat_exp.restype = C.c_double
         L.orc_kat_log.argtypes = [C.c_double]
