@@ -121,7 +121,9 @@ def main():
     from common import ref_test_model, config
 
     dist = None
-    if world > 1:
+    # EPV_BENCH_FORCE_DIST=1 under torchrun with one rank exercises the RCCL set-up and the
+    # barrier / all-reduce legs on a 1-GPU box (the shard exchange itself needs >= 2 GPUs)
+    if world > 1 or (os.environ.get("EPV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ):
         import torch.distributed as dist
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -209,7 +211,7 @@ def main():
                          "resamples_per_launch": per_launch_units, "avg_launch_ms": avg_ms,
                          "launches_timed": n_launch},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(model, tree, fp_own)
         print(json.dumps(out))
     if dist is not None:
