@@ -398,6 +398,53 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
 
 static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base);
 
+EPV_API int epv_get_capacity(epv_ctx *c, uint32_t *capacity) {
+  if (!c || !capacity || !c->have_paths) return EPV_ERR_ARG;
+  *capacity = c->S.C;
+  return EPV_OK;
+}
+
+EPV_API int epv_set_capacity(epv_ctx *c, uint32_t capacity) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (capacity < 1u) capacity = 1u;
+  if (capacity > EPV_MAX_CAP) capacity = EPV_MAX_CAP;
+  if (capacity == c->S.C) return EPV_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t n = c->S.n, B = c->S.B, E = B * n;
+  if (capacity < c->S.C) {
+    // shrinking: every resident path (either buffer: a stale proposal is overwritten before
+    // it is read, but keep the test simple) must fit
+    std::vector<uint8_t> meta(2u * E);
+    HIP_TRY(c, hipMemcpyAsync(meta.data(), c->S.meta, 2u * E, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint8_t> sel(n);
+    HIP_TRY(c, hipMemcpyAsync(sel.data(), c->S.sel, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint64_t s = 0; s < n; ++s)
+      for (uint64_t b = 0; b < B; ++b)
+        if ((meta[((uint64_t)sel[s] * n + s) * B + b] & 127u) > capacity)
+          return fail(c, EPV_ERR_CAPACITY, "a resident path has more jumps than the requested capacity");
+  }
+  double *nj = nullptr;
+  HIP_TRY(c, hipMalloc(&nj, 2u * E * capacity * sizeof(double)));
+  const uint32_t keep = std::min(capacity, c->S.C);
+  // plane (buf, b) holds C rows of n doubles: rows 0..keep-1 move to the new stride
+  for (uint64_t plane = 0; plane < 2u * B; ++plane)
+    HIP_TRY(c, hipMemcpyAsync(nj + plane * capacity * n, c->S.jumps + plane * c->S.C * n,
+                              (size_t)keep * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  const uint32_t W = (2u * capacity + 1u + 63u) / 64u;
+  uint64_t *ns = nullptr;
+  HIP_TRY(c, hipMalloc(&ns, B * c->S.phase_cap * W * sizeof(uint64_t)));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(c->S.jumps);
+  (void)hipFree(c->S.prop_states);
+  c->S.jumps = nj;
+  c->S.prop_states = ns;
+  c->S.C = capacity;
+  c->S.W = W;
+  return plan_mh(c);
+}
+
 EPV_API int epv_init_paths_indep(epv_ctx *c, uint64_t n_sites, const uint8_t *root_states,
                                  const uint8_t *leaf_states, uint64_t seed, uint32_t capacity) {
   if (!c) return EPV_ERR_ARG;

@@ -22,6 +22,22 @@ void SingleSiteSampler::check(int rc, const char *what) {
   if (rc != EPV_OK) throw std::runtime_error(std::string(what) + ": " + epv_last_error(ctx_));
 }
 
+// after an MCMC call: an overflow leaves a valid chain and complete outputs (the over-long
+// proposals were rejected), so widen the jump slots for the following calls -- what the
+// reference's std::vector paths do on their own -- and carry on
+void SingleSiteSampler::check_mcmc(int rc, const char *what) {
+  if (rc == EPV_ERR_CAPACITY) {
+    uint32_t cap = 0;
+    if (epv_get_capacity(ctx_, &cap) == EPV_OK && cap < 127u) {
+      const std::string msg = epv_last_error(ctx_);
+      check(epv_set_capacity(ctx_, cap * 2u > 127u ? 127u : cap * 2u), "epv_set_capacity");
+      capacity_events.push_back(std::string(what) + ": " + msg);
+      return;
+    }
+  }
+  check(rc, what);
+}
+
 void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &paths) {
   n_nodes_ = th.n_nodes();
   n_sites_ = paths.n_sites;
@@ -57,7 +73,7 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
   std::vector<double> Jf(B * 8), Df(B * 8);
   uint64_t n_acc = 0;
   const uint32_t base = (uint32_t)(em_iteration * (burn_in + batch));
-  check(epv_run_mcmc(ctx_, burn_in, batch, seed, base, Jf.data(), Df.data(), &n_acc), "epv_run_mcmc");
+  check_mcmc(epv_run_mcmc(ctx_, burn_in, batch, seed, base, Jf.data(), Df.data(), &n_acc), "epv_run_mcmc");
   J.assign(n_nodes_, {});
   D.assign(n_nodes_, {});
   for (size_t b = 1; b <= B; ++b) {
@@ -69,7 +85,7 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
 
 size_t SingleSiteSampler::sweeps(size_t n, uint64_t seed, uint32_t sweep_base) {
   uint64_t n_acc = 0;
-  check(epv_sweep(ctx_, n, seed, sweep_base, &n_acc), "epv_sweep");
+  check_mcmc(epv_sweep(ctx_, n, seed, sweep_base, &n_acc), "epv_sweep");
   return n_acc;
 }
 
@@ -118,7 +134,7 @@ void SingleSiteSampler::indep_sufficient_statistics(std::vector<double> &J, std:
 }
 
 void SingleSiteSampler::indep_update_paths(const double rates[2], uint64_t seed, uint32_t sweep) {
-  check(epv_indep_update_paths(ctx_, rates, seed, sweep), "epv_indep_update_paths");
+  check_mcmc(epv_indep_update_paths(ctx_, rates, seed, sweep), "epv_indep_update_paths");
 }
 
 void SingleSiteSampler::download(FlatPaths &paths) {

@@ -16,6 +16,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "epv_io.hpp"
@@ -70,8 +71,12 @@ public:
   size_t burn_in;
   size_t batch;
 
+  // capacity overflows that were absorbed by widening the device jump slots (verbose output)
+  std::vector<std::string> capacity_events;
+
 private:
   void check(int rc, const char *what);
+  void check_mcmc(int rc, const char *what);
   epv_ctx *ctx_;
   uint32_t capacity_;
   int n_nodes_ = 0;

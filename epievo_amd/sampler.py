@@ -35,7 +35,7 @@ class _Counters(C.Structure):
 
 ABI_SYMBOLS = [
     "epv_create", "epv_destroy", "epv_last_error", "epv_set_tree", "epv_set_model",
-    "epv_upload_paths", "epv_init_paths_indep", "epv_indep_expectation",
+    "epv_upload_paths", "epv_set_capacity", "epv_get_capacity", "epv_init_paths_indep", "epv_indep_expectation",
     "epv_indep_sufficient_statistics", "epv_indep_update_paths", "epv_set_global_length", "epv_set_update_range", "epv_set_halo",
     "epv_halo_phases_left", "epv_reset", "epv_sweep",
     "epv_sweep_phase", "epv_run_mcmc", "epv_run_mcmc_sums", "epv_get_sufficient_statistics", "epv_scale_jump_times",
@@ -65,6 +65,8 @@ def lib():
         L.epv_set_tree.argtypes = [vp, C.c_int, u32p, u32p, dp]
         L.epv_set_model.argtypes = [vp, dp, dp]
         L.epv_upload_paths.argtypes = [vp, C.c_uint64, u8p, u64p, dp, C.c_uint32, C.c_uint64]
+        L.epv_set_capacity.argtypes = [vp, C.c_uint32]
+        L.epv_get_capacity.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.epv_init_paths_indep.argtypes = [vp, C.c_uint64, u8p, u8p, C.c_uint64, C.c_uint32]
         L.epv_indep_expectation.argtypes = [vp, dp, dp, dp]
         L.epv_indep_sufficient_statistics.argtypes = [vp, dp, dp]
@@ -108,6 +110,8 @@ class DeviceSampler:
             raise RuntimeError("epv_create(%d) failed: no usable HIP device (this build has no "
                                "CPU fallback)" % device)
         self.n_sites = self.n_nodes = self.B = 0
+        self.auto_grow = False     # True: widen the jump slots after an overflow and carry on
+        self.capacity_events = []  # messages of the overflows that were absorbed
 
     def close(self):
         if getattr(self, "h", None):
@@ -121,6 +125,28 @@ class DeviceSampler:
         if rc != EPV_OK:
             msg = self.L.epv_last_error(self.h).decode()
             raise (CapacityError if rc == EPV_ERR_CAPACITY else EpvError)(rc, msg)
+
+    def _ck_mcmc(self, rc):
+        """after an MCMC call: a capacity overflow leaves a valid chain (the over-long proposals
+        were rejected) and complete outputs, so with auto_grow the slots are doubled for the
+        following calls -- what the reference's std::vector paths do on their own -- and the
+        call succeeds; otherwise it raises CapacityError like any other failure."""
+        if rc == EPV_ERR_CAPACITY and self.auto_grow:
+            msg = self.L.epv_last_error(self.h).decode()
+            cap = self.capacity()
+            if cap < 127:
+                self.set_capacity(min(127, 2 * cap))
+                self.capacity_events.append(msg)
+                return
+        self._ck(rc)
+
+    def capacity(self):
+        v = C.c_uint32(0)
+        self._ck(self.L.epv_get_capacity(self.h, C.byref(v)))
+        return int(v.value)
+
+    def set_capacity(self, capacity):
+        self._ck(self.L.epv_set_capacity(self.h, int(capacity)))
 
     def set_tree(self, tree):
         self.n_nodes, self.B = tree.n_nodes, tree.n_nodes - 1
@@ -160,7 +186,7 @@ class DeviceSampler:
 
     def indep_update_paths(self, rates, seed, sweep=0):
         r = np.ascontiguousarray(rates, np.float64)
-        self._ck(self.L.epv_indep_update_paths(self.h, _p(r, C.c_double), seed, sweep))
+        self._ck_mcmc(self.L.epv_indep_update_paths(self.h, _p(r, C.c_double), seed, sweep))
 
     def set_update_range(self, first, last):
         self._ck(self.L.epv_set_update_range(self.h, first, last))
@@ -178,7 +204,7 @@ class DeviceSampler:
 
     def sweep(self, n_sweeps, seed, sweep_base=0):
         nacc = C.c_uint64(0)
-        self._ck(self.L.epv_sweep(self.h, n_sweeps, seed, sweep_base, C.byref(nacc)))
+        self._ck_mcmc(self.L.epv_sweep(self.h, n_sweeps, seed, sweep_base, C.byref(nacc)))
         return int(nacc.value)
 
     def sweep_phase(self, colour, seed, sweep):
@@ -189,8 +215,8 @@ class DeviceSampler:
     def run_mcmc(self, burn_in, batch, seed, sweep_base=0, average=True):
         J, D = np.zeros(self.B * 8), np.zeros(self.B * 8)
         nacc = C.c_uint64(0)
-        self._ck(self.L.epv_run_mcmc_sums(self.h, burn_in, batch, seed, sweep_base, int(average),
-                                          _p(J, C.c_double), _p(D, C.c_double), C.byref(nacc)))
+        self._ck_mcmc(self.L.epv_run_mcmc_sums(self.h, burn_in, batch, seed, sweep_base, int(average),
+                                               _p(J, C.c_double), _p(D, C.c_double), C.byref(nacc)))
         return J, D, int(nacc.value)
 
     def suffstats(self):
@@ -258,6 +284,7 @@ class SingleSiteSampler:
         self.SAMPLE_ROOT = False  # hard-wired false in the reference (SingleSiteSampler.cpp:441)
         self.capacity = capacity
         self.dev = DeviceSampler(device)
+        self.dev.auto_grow = True     # paths grow on demand, as the reference's vectors do
         self._uploaded = False
 
     def reset(self, model, tree, paths=None):

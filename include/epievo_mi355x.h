@@ -79,6 +79,15 @@ int epv_upload_paths(epv_ctx *ctx, uint64_t n_sites, const uint8_t *init_state,
                      const uint64_t *offsets, const double *jumps, uint32_t capacity,
                      uint64_t global_site_offset);
 
+/* Change the number of jump slots per (site, branch) of the RESIDENT paths, on the device
+ * (no host round trip): the jump planes are re-strided, states and cached log-likelihoods
+ * stay valid.  The reference's std::vector paths grow on demand; this is the equivalent a
+ * wrapper calls after EPV_ERR_CAPACITY (the run that reported it is a valid chain on the
+ * histories with at most `capacity` jumps per branch).  Fails with EPV_ERR_CAPACITY when a
+ * resident path has more jumps than `capacity`; capacity is clamped to 1..127. */
+int epv_set_capacity(epv_ctx *ctx, uint32_t capacity);
+int epv_get_capacity(epv_ctx *ctx, uint32_t *capacity);
+
 /* initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device, for the
  * two-node tree of one branch (epv_set_tree with n_nodes = 2 and epv_set_model first):
  * every interior site gets an independent end-conditioned path root[i] -> leaf[i] by

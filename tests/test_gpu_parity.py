@@ -173,3 +173,35 @@ def test_init_paths_indep_bit_exact(n, seed):
     o.reset()
     assert d.sweep(2, 5) == o.sweep(0) + o.sweep(1)
     assert orc.paths_equal(d.paths(), o.paths())
+
+
+def test_set_capacity_and_auto_grow_match_oracle():
+    """epv_set_capacity re-strides the resident jump planes on the device; with auto_grow the
+    Python/C++ mirrors absorb an overflow by doubling the slots, and the chain stays the
+    oracle's chain at the same sequence of capacities"""
+    from epievo_amd.sampler import CapacityError
+    model, tree, fp = simulate("pair", 2000, seed=8)
+    cap = int(fp.counts().max())
+    d = _dev(tree, model, fp, capacity=cap)
+    d.reset()
+    before = d.paths()
+    assert d.capacity() == cap
+    d.set_capacity(cap + 5)                          # grow: nothing changes but the stride
+    assert d.capacity() == cap + 5 and orc.paths_equal(d.paths(), before)
+    with pytest.raises(CapacityError):
+        d.set_capacity(cap - 1)                      # a resident path would not fit
+    d.set_capacity(cap)                              # shrink back (every path fits)
+    assert orc.paths_equal(d.paths(), before)
+    d.auto_grow = True
+    o = orc.Oracle(tree, model, fp, "B", cap=cap, seed=4)
+    o.reset()
+    caps = [cap]
+    for w in range(4):
+        assert d.sweep(1, 4, sweep_base=w) == o.sweep(w)   # no CapacityError: absorbed
+        assert orc.paths_equal(d.paths(), o.paths())
+        caps.append(d.capacity())
+        o.set_rung("B", caps[-1])
+    assert caps[-1] >= 2 * cap and d.capacity_events and "rejected" in d.capacity_events[0]
+    assert d.counters()["overflow"] == o.counters()["overflow"] > 0
+    # tri_llh cache survived the re-striding
+    assert np.array_equal(d.tri_llh(), o.tri_llh())
