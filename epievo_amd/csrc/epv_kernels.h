@@ -455,6 +455,7 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
     //         rejection with dense lanes instead of making 64 lanes wait for 3.
     double log_prob = 0.0, orig_proposal = 0.0;
     unsigned long long dirty = 0ull;   // bit (node-1) & 63, flushed every 64 branches
+    unsigned long long multi = 0ull;   // ... of those, the branches with more than one segment
     {
       const uint32_t root_state = run ? (uint32_t)(S.meta[meta_idx(S, selM, 0u, site)] >> 7) : 0u;
       for (uint32_t node = 1u; node < S.N; ++node) {
@@ -529,30 +530,42 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
           S.meta[meta_idx(S, selM ^ 1u, b, site)] = (uint8_t)(start_state << 7);
           regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children
           orig_proposal += lp;
-          if (!clean) dirty |= 1ull << (b & 63u);
+          if (!clean) {
+            dirty |= 1ull << (b & 63u);
+            if (K > 1u) multi |= 1ull << (b & 63u);
+          }
         }
         // flush the dirty (site, branch) pairs of the last <= 64 branches: ONE atomic per
-        // wave reserves the slots, the lanes fill them in
+        // wave reserves the slots, the lanes fill them in.  A shard's region is filled from
+        // BOTH ends -- single-segment branches from the front, multi-segment ones from the
+        // back (counts packed lo/hi in one word) -- so that the waves of the jumps kernel,
+        // which take consecutive tasks, hold lanes with similar loop counts.
         if ((b & 63u) == 63u || node + 1u == S.N) {
-          const uint32_t mine = (uint32_t)__popcll(dirty);
-          const uint32_t incl_t = wave_incl_scan_u32(mine);
-          const uint32_t total = __shfl(incl_t, 63);
-          if (total) {
+          const uint32_t mineB = (uint32_t)__popcll(dirty & multi);
+          const uint32_t mineA = (uint32_t)__popcll(dirty) - mineB;
+          const uint32_t inclA = wave_incl_scan_u32(mineA), inclB = wave_incl_scan_u32(mineB);
+          const uint32_t totalA = __shfl(inclA, 63), totalB = __shfl(inclB, 63);
+          if (totalA | totalB) {
             unsigned long long base = 0ull;
             const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
             if (lane == 0)
-              base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)], (unsigned long long)total);
-            base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0) << 32) |
-                   (unsigned long long)__shfl((uint32_t)base, 0);
-            unsigned long long slot = (unsigned long long)shard * S.task_cap + base + (incl_t - mine);
+              base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)],
+                               (unsigned long long)totalA | ((unsigned long long)totalB << 32));
+            const uint32_t baseA = __shfl((uint32_t)base, 0), baseB = __shfl((uint32_t)(base >> 32), 0);
+            unsigned long long *region = S.tasks + (unsigned long long)shard * S.task_cap;
+            unsigned long long slotA = (unsigned long long)baseA + (inclA - mineA);
+            unsigned long long slotB = S.task_cap - 1ull - ((unsigned long long)baseB + (inclB - mineB));
             unsigned long long d = dirty;
             while (d) {
               const uint32_t bit = (uint32_t)(__ffsll((long long)d) - 1);
               d &= d - 1ull;
-              S.tasks[slot++] = ((unsigned long long)((b & ~63u) + bit) << 40) | site;
+              const unsigned long long t = ((unsigned long long)((b & ~63u) + bit) << 40) | site;
+              if ((multi >> bit) & 1ull) region[slotB--] = t;
+              else region[slotA++] = t;
             }
           }
           dirty = 0ull;
+          multi = 0ull;
         }
       }
     }
@@ -602,7 +615,9 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
            *c_nk = c_nk_[wave], *c_res = c_res_[wave], *c_tw = c_tw_[wave];
   const bool indep = indep_r0 > 0.0;   // epv_indep_update_paths: rates are not context dependent
   const uint32_t shard = blockIdx.y;   // one task-list region per counter shard
-  const unsigned long long n_tasks = counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)];
+  // the region is filled from both ends (front: single-segment branches, back: the others)
+  const unsigned long long packed = counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)];
+  const unsigned long long n_front = packed & 0xffffffffull, n_tasks = n_front + (packed >> 32);
   const unsigned long long *tasks = S.tasks + (unsigned long long)shard * S.task_cap;
   const uint64_t n = S.n;
   const uint32_t B = S.B, C = S.C;
@@ -628,7 +643,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
     unsigned long long word = 0ull;
     bool ovf = false;
     if (active) {
-      const unsigned long long task = tasks[ti];
+      const unsigned long long task = ti < n_front ? tasks[ti] : tasks[S.task_cap - 1ull - (ti - n_front)];
       site = task & 0xffffffffffull;
       b = (uint32_t)(task >> 40);
       node = b + 1u;
@@ -836,7 +851,8 @@ __global__ __launch_bounds__(256) void epv_mh_accept_kernel(
   // the task lists of this phase have been consumed (stream order): fold their lengths
   // into the running total and clear them for the next propose kernel
   if (blockIdx.x == 0 && threadIdx.x < EPV_SHARDS) {
-    counters[EPV_CNT_IDX(EPV_CNT_COOP, threadIdx.x)] += counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)];
+    const unsigned long long packed = counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)];
+    counters[EPV_CNT_IDX(EPV_CNT_COOP, threadIdx.x)] += (packed & 0xffffffffull) + (packed >> 32);
     counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)] = 0ull;
   }
 }
