@@ -11,6 +11,13 @@ GOLDEN = os.path.join(HERE, "golden")
 # the reference's test/test.param and test/tree.nwk, restated as data (2 + 1 lines)
 TEST_PARAM_TEXT = "stationary\t0.844912\t0.893359\nbaseline\t-0.8\t-1.8\n"
 TREE_NWK_TEXT = "((C:0.03,D:0.06)E:0.02,F:0.1)G:0.0;\n"
+# further topologies for the parity tests: a star (root with four children), a tree with an
+# internal trifurcation and one long branch, and a 6-leaf caterpillar
+EXTRA_TREES = {
+    "star4": "(A:0.1,B:0.2,C:0.05,D:0.3)R:0.0;\n",
+    "multi": "((A:0.1,B:0.1,C:0.2)X:0.1,(D:0.3,E:0.05)Y:0.2,F:0.8)R:0.0;\n",
+    "cat6": "(((((A:0.05,B:0.07)U:0.04,C:0.1)V:0.03,D:0.15)W:0.06,E:0.2)Z:0.02,F:0.25)R:0.0;\n",
+}
 
 
 def _tmp(name, text):
@@ -39,6 +46,8 @@ def config(name):
         return host.Tree.single_branch(1.0)
     if name == "bal16":
         return host.Tree.balanced(16, 0.05)
+    if name in EXTRA_TREES:
+        return host.Tree.read(_tmp(name + ".nwk", EXTRA_TREES[name]))
     raise KeyError(name)
 
 

@@ -166,4 +166,6 @@ if __name__ == "__main__":
         for n in (16, 64, 1000):
             for seed in (1, 42):
                 case(cfg, n, seed)
+    for cfg in ("star4", "multi", "cat6"):     # multifurcations, a long branch, a deep tree
+        case(cfg, 200, 7)
     kat()

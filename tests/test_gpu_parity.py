@@ -21,7 +21,8 @@ def _dev(tree, model, fp, capacity=16):
 
 @pytest.mark.parametrize("cfg,n", [("tree", 64), ("tree", 1000), ("pair", 1000), ("tree", 20011),
                                    ("pair", 20011), ("bal16", 3000), ("tree", 3), ("tree", 4),
-                                   ("tree", 5), ("pair", 7)])
+                                   ("tree", 5), ("pair", 7), ("star4", 3000), ("multi", 3000),
+                                   ("cat6", 3000)])
 def test_reset_and_roundtrip(cfg, n):
     model, tree, fp = simulate(cfg, n, seed=3)
     d = _dev(tree, model, fp)
@@ -39,7 +40,8 @@ def test_reset_and_roundtrip(cfg, n):
 @pytest.mark.parametrize("cfg,n,sweeps", [("tree", 64, 3), ("tree", 1000, 3), ("pair", 1000, 3),
                                           ("tree", 20011, 2), ("pair", 20011, 2),
                                           ("bal16", 3000, 2), ("tree", 3, 2), ("tree", 4, 2),
-                                          ("tree", 5, 2), ("pair", 6, 2)])
+                                          ("tree", 5, 2), ("pair", 6, 2), ("star4", 3000, 3),
+                                          ("multi", 3000, 3), ("cat6", 3000, 3)])
 def test_sweeps_bit_exact(cfg, n, sweeps):
     model, tree, fp = simulate(cfg, n, seed=5)
     seed = 0x1234567890abcdef
@@ -56,7 +58,7 @@ def test_sweeps_bit_exact(cfg, n, sweeps):
     assert d.counters()["overflow"] == o.counters()["overflow"] == 0
 
 
-@pytest.mark.parametrize("cfg,n", [("tree", 5000), ("pair", 5000)])
+@pytest.mark.parametrize("cfg,n", [("tree", 5000), ("pair", 5000), ("multi", 4000), ("cat6", 4000)])
 def test_run_mcmc_bit_exact(cfg, n):
     model, tree, fp = simulate(cfg, n, seed=11)
     d = _dev(tree, model, fp)

@@ -24,7 +24,7 @@ def _load(path):
 
 
 def test_fixture_set_is_complete():
-    assert len(CASES) == 12
+    assert len(CASES) == 15
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c)[:-4] for c in CASES])
