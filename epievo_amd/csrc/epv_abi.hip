@@ -46,6 +46,9 @@ struct epv_ctx {
   EpvIndepConst *d_indep = nullptr;  // [N] constants of the site-independent model
   // launch shape of the MH kernel
   uint32_t mh_threads = 64, pool_entries = 0;
+  bool mh_gpool = false;        // record pool of the propose kernel in global memory (large trees)
+  double *d_gpool = nullptr;
+  uint64_t gpool_cap = 0;       // doubles allocated
   uint32_t tasks_per_wave = 32;  // epv_mh_jumps_kernel: lanes of a wave that own a task
   double kbar = 0.0;  // mean jumps per (site, branch) of the uploaded paths
   size_t mh_lds = 0;
@@ -93,16 +96,38 @@ int plan_mh(epv_ctx *c) {
   const uint64_t worst = (uint64_t)B * (2u * C + 2u);
   // per wave: node table N*64 u32 (rounded to 16 B) + pool of 16-byte records
   const size_t fixed = const_lds_bytes(N) + (((size_t)N * 64u * 4u + 15u) & ~(size_t)15u);
-  if (fixed + worst * 16u > 160u * 1024u)
-    return fail(c, EPV_ERR_ARG, "tree/capacity too large for the 160 KiB LDS record pool");
+  if (fixed > 150u * 1024u) return fail(c, EPV_ERR_ARG, "tree too large for the 160 KiB LDS node table");
   // typical demand of 64 lanes: B * (2 kbar + 2) records each, with a 30 % margin
   const uint64_t typical = (uint64_t)(64.0 * B * (2.0 * c->kbar + 2.0) * 1.3) + 32u;
-  const uint64_t max_fit = (160u * 1024u - fixed) / 16u;
-  const uint64_t pool = std::min<uint64_t>(std::max<uint64_t>(worst, typical), max_fit);
-  const size_t lds = fixed + (size_t)pool * 16u;
+  const uint64_t max_fit = fixed + 16u < 160u * 1024u ? (160u * 1024u - fixed) / 16u : 0u;
+  const uint64_t want = std::max<uint64_t>(worst, typical);
   c->mh_threads = 64;
+  // LDS pool while it leaves >= 8 waves per CU (2 per SIMD); otherwise a global-memory slab
+  // per block (the working set of the resident waves stays in L2 / Infinity Cache)
+  const bool lds_ok = want <= max_fit && (fixed + std::min(want, max_fit) * 16u) * 8u <= 160u * 1024u;
+  // tuning knobs (tools/ab_env.py): EPV_FORCE_LDS_POOL / EPV_FORCE_GLOBAL_POOL
+  const bool use_lds = std::getenv("EPV_FORCE_GLOBAL_POOL") ? false
+                       : std::getenv("EPV_FORCE_LDS_POOL") ? want <= max_fit : lds_ok;
+  if (use_lds) {
+    const uint64_t pool = std::min(want, max_fit);
+    c->mh_gpool = false;
+    c->pool_entries = (uint32_t)pool;
+    c->mh_lds = fixed + (size_t)pool * 16u;
+    return EPV_OK;
+  }
+  const uint64_t pool = std::max<uint64_t>(worst, 2u * typical);
+  const uint64_t blocks = (c->S.phase_cap + 63u) / 64u;
+  const uint64_t need = blocks * pool * 2u;
+  if (need > c->gpool_cap) {
+    dfree(c->d_gpool);
+    c->gpool_cap = 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc(&c->d_gpool, need * sizeof(double)));
+    c->gpool_cap = need;
+  }
+  c->mh_gpool = true;
   c->pool_entries = (uint32_t)pool;
-  c->mh_lds = lds;
+  c->mh_lds = fixed;
   return EPV_OK;
 }
 
@@ -186,9 +211,14 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     ++c->ev_used;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
   }
-  hipLaunchKernelGGL(epv_mh_propose_kernel, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds,
-                     c->stream, c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32),
-                     sweep, first, last, c->pool_entries, c->d_counters);
+  if (c->mh_gpool)
+    hipLaunchKernelGGL(epv_mh_propose_kernel<true>, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds,
+                       c->stream, c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       sweep, first, last, c->pool_entries, c->d_counters, c->d_gpool);
+  else
+    hipLaunchKernelGGL(epv_mh_propose_kernel<false>, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds,
+                       c->stream, c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       sweep, first, last, c->pool_entries, c->d_counters, (double *)nullptr);
   {
     // one lane per dirty (site, branch) pair; the count is only known on the device, so
     // launch a grid that covers the typical case and grid-stride over the rest
@@ -261,7 +291,9 @@ EPV_API epv_ctx *epv_create(int device_id) {
     return nullptr;
   }
   // the MH kernel asks for more dynamic LDS than the 64 KiB default
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return c;
 }
@@ -272,7 +304,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep);
+  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->stream);

@@ -341,18 +341,26 @@ __device__ __forceinline__ double gtp(double r0, double r1, double h, double den
 // its lanes.
 #define EPV_MH_THREADS 256
 
+// GPOOL = false: the record pool lives in LDS (short trees: ~13 KB per wave, 12 waves/CU).
+// GPOOL = true : the pool is a per-block slab in global memory with the very same indexing.
+//   On a large tree the pool alone (64 lanes x (N-1) branches x ~2 records x 16 B = 84 KB for
+//   the 16-leaf tree) would leave ONE wave per CU; with the slab in HBM/L2 only the node table
+//   stays in LDS and the kernel keeps its 3 waves/SIMD.
+template <bool GPOOL>
 __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
-    uint64_t first, uint64_t last, uint32_t pool_entries, unsigned long long *counters) {
+    uint64_t first, uint64_t last, uint32_t pool_entries, unsigned long long *counters,
+    double *gpool) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   double *s_const = s_mem;                     // 20 + N doubles (padded to even)
   const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
   const uint32_t wave = threadIdx.x >> 6;
   const int lane = epv_lane();
   const uint32_t regA_dbl = (S.N * 64u + 1u) / 2u;   // N * 64 u32
-  const uint32_t wave_dbl = ((regA_dbl + 1u) & ~1u) + pool_entries * 2u;
+  const uint32_t wave_dbl = ((regA_dbl + 1u) & ~1u) + (GPOOL ? 0u : pool_entries * 2u);
   uint32_t *regA = reinterpret_cast<uint32_t *>(s_mem + const_dbl + (size_t)wave * wave_dbl);
-  double *pool = s_mem + const_dbl + (size_t)wave * wave_dbl + ((regA_dbl + 1u) & ~1u);
+  double *pool = GPOOL ? gpool + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * pool_entries * 2u
+                       : s_mem + const_dbl + (size_t)wave * wave_dbl + ((regA_dbl + 1u) & ~1u);
   stage_constants(S, s_const);
   const double *s_rates = s_const;
   const double *s_blen = s_const + 20;
