@@ -171,13 +171,13 @@ int launch_suffstats(epv_ctx *c, int *which) {
   const uint32_t V = c->S.B * 16u;
   uint64_t own_lo = 0, own_hi = 0;
   owned_range(c, &own_lo, &own_hi);
-  hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)nb), dim3(256), const_lds_bytes(c->S.N),
+  hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)nb, c->S.B), dim3(256), const_lds_bytes(c->S.N),
                      c->stream, c->S, own_lo, own_hi, c->d_partial[0]);
   uint64_t m = nb;
   int cur = 0;
   while (m > 1) {
     const uint64_t mb = (m + 255u) / 256u;
-    hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb, V / 16u), dim3(256), 0, c->stream,
                        c->d_partial[cur], m, V, c->d_partial[cur ^ 1]);
     m = mb;
     cur ^= 1;
@@ -592,8 +592,8 @@ int indep_stats(epv_ctx *c, const double *rates, uint32_t what, double *J, doubl
   int cur = 0;
   while (m > 1) {
     const uint64_t mb = (m + 255u) / 256u;
-    hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb), dim3(256), 0, c->stream, c->d_partial[cur], m,
-                       V16, c->d_partial[cur ^ 1]);
+    hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb, V16 / 16u), dim3(256), 0, c->stream,
+                       c->d_partial[cur], m, V16, c->d_partial[cur ^ 1]);
     m = mb;
     cur ^= 1;
   }

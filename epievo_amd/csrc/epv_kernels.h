@@ -1177,60 +1177,54 @@ __global__ __launch_bounds__(256) void epv_reset_kernel(EpvDev S) {
 __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t first,
                                                            uint64_t last, double *partial) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
-  __shared__ double s_part[2][4][16];
+  __shared__ double s_part[4][16];
   stage_constants(S, s_mem);
   const double *s_blen = s_mem + 20;
   const int lane = epv_lane();
   const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t b = blockIdx.y;          // one branch per block row: B x more blocks in flight
   const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool on = site >= first && site <= last && site >= 1 && site + 1 < S.n;
-  uint32_t sl = 0, sm = 0, sr = 0;
-  if (on) { sl = S.sel[site - 1]; sm = S.sel[site]; sr = S.sel[site + 1]; }
-  for (uint32_t b = 0; b < S.B; ++b) {
-    Acc8 A;
-    acc_clear(A);
-    if (on) {
-      const PathRef L = path_ref(S, sl, b, site - 1), M = path_ref(S, sm, b, site),
-                    R = path_ref(S, sr, b, site + 1);
-      merge3(L, M, R, S.n, s_blen[b + 1], A);
-    }
-    double v[16];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { v[c] = (double)A.j[c]; v[8 + c] = A.d[c]; }
-    int idx;
-    const double tot = wave_tree_sum16(v, lane, idx);
-    if (lane < 16) s_part[b & 1u][wave][idx] = tot;
-    __syncthreads();
-    if (threadIdx.x < 16) {
-      const double(*p)[16] = s_part[b & 1u];
-      partial[((uint64_t)blockIdx.x * S.B + b) * 16u + threadIdx.x] =
-          (p[0][threadIdx.x] + p[1][threadIdx.x]) + (p[2][threadIdx.x] + p[3][threadIdx.x]);
-    }
+  Acc8 A;
+  acc_clear(A);
+  if (on) {
+    const uint32_t sl = S.sel[site - 1], sm = S.sel[site], sr = S.sel[site + 1];
+    const PathRef L = path_ref(S, sl, b, site - 1), M = path_ref(S, sm, b, site),
+                  R = path_ref(S, sr, b, site + 1);
+    merge3(L, M, R, S.n, s_blen[b + 1], A);
   }
+  double v[16];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { v[c] = (double)A.j[c]; v[8 + c] = A.d[c]; }
+  int idx;
+  const double tot = wave_tree_sum16(v, lane, idx);
+  if (lane < 16) s_part[wave][idx] = tot;
+  __syncthreads();
+  if (threadIdx.x < 16)
+    partial[((uint64_t)blockIdx.x * S.B + b) * 16u + threadIdx.x] =
+        (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
 }
 
 // one level of the tree: in[m][V] -> out[ceil(m/256)][V] (V a multiple of 16), each block
-// sums 256 consecutive (aligned) entries of every value column in balanced order
+// sums 256 consecutive (aligned) entries of one group of 16 value columns (blockIdx.y) in
+// balanced order
 __global__ __launch_bounds__(256) void epv_tree_reduce_kernel(const double *in, uint64_t m,
                                                               uint32_t V, double *out) {
-  __shared__ double s_part[2][4][16];
+  __shared__ double s_part[4][16];
   const int lane = epv_lane();
   const uint32_t wave = threadIdx.x >> 6;
   const uint64_t idx_in = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  for (uint32_t g = 0; g < V / 16u; ++g) {
-    double v[16];
+  const uint32_t g = blockIdx.y;
+  double v[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) v[c] = idx_in < m ? in[idx_in * V + g * 16u + c] : 0.0;
-    int idx;
-    const double tot = wave_tree_sum16(v, lane, idx);
-    if (lane < 16) s_part[g & 1u][wave][idx] = tot;
-    __syncthreads();
-    if (threadIdx.x < 16) {
-      const double(*p)[16] = s_part[g & 1u];
-      out[(uint64_t)blockIdx.x * V + g * 16u + threadIdx.x] =
-          (p[0][threadIdx.x] + p[1][threadIdx.x]) + (p[2][threadIdx.x] + p[3][threadIdx.x]);
-    }
-  }
+  for (int c = 0; c < 16; ++c) v[c] = idx_in < m ? in[idx_in * V + g * 16u + c] : 0.0;
+  int idx;
+  const double tot = wave_tree_sum16(v, lane, idx);
+  if (lane < 16) s_part[wave][idx] = tot;
+  __syncthreads();
+  if (threadIdx.x < 16)
+    out[(uint64_t)blockIdx.x * V + g * 16u + threadIdx.x] =
+        (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
 }
 
 // acc[i] += one[i]  (J_all_sites += J_one_site, SingleSiteSampler.cpp:582-586)
