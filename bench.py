@@ -41,6 +41,25 @@ def algorithmic_bytes_per_resample(kbar, n_branches):
     return 2.0 * (1.0 + 4.0 + 8.0 * kbar) + 16.0 / n_branches
 
 
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota
+    (a GPU box hands each job a share of a much larger host)."""
+    n = len(os.sched_getaffinity(0))
+    for qf, pf in (("/sys/fs/cgroup/cpu.max", None),
+                   ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if pf is None:
+                quota, period = open(qf).read().split()[:2]
+            else:
+                quota, period = open(qf).read().strip(), open(pf).read().strip()
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 def cpu_baseline(model, tree, fp, budget_s=20.0):
     """The reference's own CPU path (oracle/_ref, the unmodified libepievo built in the
     authoring container) or, when that .so is absent, the bit-identical C restatement
@@ -75,8 +94,14 @@ def cpu_baseline(model, tree, fp, budget_s=20.0):
     omp = os.path.join(ROOT, "oracle", "liborc_omp.so")
     if os.path.exists(omp):
         try:
+            cores = effective_cpus()
+            os.environ["OMP_NUM_THREADS"] = str(cores)     # read when libgomp is loaded ...
             orc._orc, orc.ORC_SO = None, omp
-            cores = len(os.sched_getaffinity(0))
+            try:                                            # ... or set on an already loaded one
+                import ctypes
+                ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+            except OSError:
+                pass
             o = orc.Oracle(tree, model, sub, "B", cap=16, seed=SEED)
             o.reset()
             t0, k2 = time.perf_counter(), 0
