@@ -800,7 +800,13 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
 //  the proposal into the site's other buffer.  No record pool here, so this part runs
 //  at full occupancy.
 // =========================================================================
-__global__ __launch_bounds__(256) void epv_mh_accept_kernel(
+// 6 waves/SIMD (<= 80 VGPRs) = 6 blocks per CU, matching the 24 KB of LDS per block: the
+// 1302 blocks of a 1e6-site phase then fit the 1536 slots in ONE round (at the natural 92
+// VGPRs there are 1280 slots and 22 blocks run alone in a second round: +15 us)
+#ifndef EPV_ACCEPT_WAVES
+#define EPV_ACCEPT_WAVES 6
+#endif
+__global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
     uint64_t first, uint64_t last, uint64_t own_first, uint64_t own_last,
     unsigned long long *counters) {
