@@ -534,7 +534,8 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
               seg_start = seg_end;
             }
           }
-          if (K & 63u) states[(K - 1u) >> 6] = word;
+          // only a dirty branch is ever read back (by epv_mh_jumps_kernel)
+          if ((K & 63u) && !clean) states[(K - 1u) >> 6] = word;
           // proposal so far: no jumps; epv_mh_jumps_kernel fills dirty branches in
           S.meta[meta_idx(S, selM ^ 1u, b, site)] = (uint8_t)(start_state << 7);
           regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children

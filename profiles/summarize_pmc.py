@@ -22,7 +22,9 @@ def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"].split("(")[0]
+            name = name[5:] if name.startswith("void ") else name   # templates: "void k<false>"
+            acc[name.split("<")[0]].append(float(r["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v) * 1024.0) for k, v in acc.items()}
 
 

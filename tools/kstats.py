@@ -23,6 +23,7 @@ def rows_from(path):
 acc = collections.defaultdict(list)
 for name, us in rows_from(sys.argv[1]):
     name = name.split("(")[0]
+    name = (name[5:] if name.startswith("void ") else name).split("<")[0]
     if name.startswith("_Z"):
         import re
         m = re.match(r"_Z(\d+)", name)
