@@ -204,33 +204,53 @@ __device__ __forceinline__ double triple_llh(const EpvDev &S, const double *s_mo
 // ------------------------------------------------ forward rejection trial
 enum { TRIAL_FAIL = 0, TRIAL_OK = 1, TRIAL_OVERFLOW = 2 };
 
-// forward_sampling (EndCondSampling.cpp:466-476) for trial t of segment (node,k):
-// hold times ~ Exp(rate of the current state) = -log(1-u)/rate until T is passed.
+// One trial t of the end-conditioned sampler of segment (node,k), start state a0, target `end`:
+//   a0 == end  forward_sampling (EndCondSampling.cpp:466-476): hold times ~ Exp(rate of the
+//              current state) = -log(1-u)/rate until T is passed;
+//   a0 != end  end_cond_sampling_Nielsen (EndCondSampling.cpp:583-617): the first jump from the
+//              truncated exponential -log(1 - u0 (1 - exp(-rate_a T)))/rate_a (`trunc` = the
+//              bracket, the same for every trial of the segment), then forward sampling from
+//              the other state.  Same conditional law as the reference's hot-path forward
+//              rejection, but the acceptance probability does not vanish with T: a flip on a
+//              short branch costs ~1 trial instead of ~1/P(a->b) = 1e2..1e5.
 // `u0` is the trial's first draw (its Philox block is shared, see epv_philox.h); later
 // draws come from the trial's own blocks.  `room` = jump slots left in this path.
 // Jump times (+start_time) are written to dst[0], dst[stride], ... for the first
 // `max_store` jumps only (0 = store nothing); the count is always complete.
 //
-// Shortcut (execution only, results unchanged): ~95 % of trials on short branches end
-// at the first draw because no jump falls inside the segment, i.e. 1-u0 <= exp(-rate*T).
-// `nojump0/1` = that bound for start state 0/1 from a float exp, shrunk by 1e-4 -- far
-// more than the float error (~1e-5 for rate*T < 40) and astronomically more than the
-// fp64 rounding of the exact test -- so "1-u0 < nojump" PROVES the exact computation
-// -log(1-u0)/rate >= T without evaluating log or the division.  Everything else takes
-// the exact path below, so the outcome is always the one the oracle computes.
+// Shortcut (execution only, results unchanged): most trials on short branches end at the
+// first hold time because no (further) jump falls inside the segment, i.e.
+// 1-u <= exp(-rate*T).  `nojump0/1` = that bound for state 0/1 from a float exp, shrunk by
+// 1e-4 -- far more than the float error (~1e-5 for rate*T < 40) and astronomically more than
+// the fp64 rounding of the exact test -- so "1-u < nojump" PROVES the exact computation
+// -log(1-u)/rate >= T (>= the time left) without evaluating log or the division.
+// Everything else takes the exact path below, so the outcome is always the oracle's.
 __device__ __forceinline__ int run_trial(uint32_t seed_lo, uint32_t seed_hi, uint32_t gsite,
                                          uint32_t sweep, uint32_t node, uint32_t k, uint32_t t,
                                          double u0, uint32_t a0, uint32_t end, double T, double r0,
-                                         double r1, double nojump0, double nojump1, uint32_t room,
-                                         double *dst, uint64_t stride, uint32_t max_store,
+                                         double r1, double nojump0, double nojump1, double trunc,
+                                         uint32_t room, double *dst, uint64_t stride, uint32_t max_store,
                                          double start_time, uint32_t &nj_out) {
   nj_out = 0;
-  if (1.0 - u0 < (a0 ? nojump1 : nojump0)) return (a0 == end) ? TRIAL_OK : TRIAL_FAIL;
   uint32_t nj = 0, a = a0, d = 0;
   double tau = 0.0;
   epv_block2 blk;
   blk.d0 = 0.0; blk.d1 = 0.0;
   double u = u0;
+  if (a0 != end) {
+    tau = -epv_log(1.0 - u0 * trunc) / (a0 ? r1 : r0);
+    if (!(tau < T)) return TRIAL_FAIL;   // a draw within rounding of 1: redraw (oracle: same guard)
+    if (room == 0u) return TRIAL_OVERFLOW;
+    a ^= 1u;
+    if (max_store > 0u) dst[0] = tau + start_time;
+    nj = 1u;
+    blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, t, 0u);
+    u = blk.d0;
+    d = 1u;
+    if (1.0 - u < (a ? nojump1 : nojump0)) { nj_out = 1u; return TRIAL_OK; }   // a == end now
+  } else if (1.0 - u0 < (a0 ? nojump1 : nojump0)) {
+    return TRIAL_OK;
+  }
   int outcome;
   for (;;) {
     tau += -epv_log(1.0 - u) / (a ? r1 : r0);
@@ -263,18 +283,21 @@ __device__ __forceinline__ double first_draw(uint32_t seed_lo, uint32_t seed_hi,
 }
 
 // Evaluate trials t0 .. t0+W-1 of one segment IN ORDER and return the first one that does
-// not fail (its index in t_out), or TRIAL_FAIL when all W fail.  Two-level to keep the
-// lanes of a wave together: a cheap scan classifies each trial by its first draw alone
-// (no jump inside the segment: success if the end state equals the start state, failure
-// otherwise -- exact thanks to run_trial's guard band), and only a trial that does jump
-// is evaluated exactly.  On a short branch ~95 % of trials never leave the scan.
+// not fail (its index in t_out), or TRIAL_FAIL when all W fail.  For a segment that keeps
+// its state the scan is two-level to keep the lanes of a wave together: a cheap pass
+// classifies each trial by its first draw alone (no jump inside the segment: success --
+// exact thanks to run_trial's guard band), and only a trial that does jump is evaluated
+// exactly.  On a short branch ~95 % of trials never leave the scan.  A segment that changes
+// state (Nielsen) evaluates each trial exactly; nearly every one succeeds.
 __device__ __forceinline__ int scan_trials(uint32_t seed_lo, uint32_t seed_hi, uint32_t gsite,
                                            uint32_t sweep, uint32_t node, uint32_t k, uint32_t t0,
                                            uint32_t W, uint32_t a0, uint32_t end, double T, double r0,
-                                           double r1, uint32_t room, double *dst, uint64_t stride,
-                                           uint32_t max_store, double start_time, uint32_t &t_out,
-                                           uint32_t &nj_out) {
-  const double bound = nojump_bound(T * (a0 ? r1 : r0));
+                                           double r1, double trunc, uint32_t room, double *dst,
+                                           uint64_t stride, uint32_t max_store, double start_time,
+                                           uint32_t &t_out, uint32_t &nj_out) {
+  const bool flip = a0 != end;
+  // no-(further-)jump bound of the state the chain waits in: a0, or `end` after the first jump
+  const double bound = nojump_bound(T * (end ? r1 : r0));
   uint32_t t = t0;
   const uint32_t t_end = t0 + W;
   nj_out = 0;
@@ -294,16 +317,16 @@ __device__ __forceinline__ int scan_trials(uint32_t seed_lo, uint32_t seed_hi, u
         }
         u = (t & 1u) ? fb.d1 : fb.d0;
       }
-      if (1.0 - u < bound) {              // provably no jump in this trial
-        if (a0 == end) { t_out = t; nj_out = 0; return TRIAL_OK; }
-      } else {
-        cand = true;
-        break;
+      if (!flip && 1.0 - u < bound) {     // provably no jump in this trial: the state is kept
+        t_out = t; nj_out = 0; return TRIAL_OK;
       }
+      cand = true;
+      break;
     }
     if (!cand) return TRIAL_FAIL;
-    const int oc = run_trial(seed_lo, seed_hi, gsite, sweep, node, k, t, u, a0, end, T, r0, r1, 0.0,
-                             0.0, room, dst, stride, max_store, start_time, nj_out);
+    const double nb = flip ? bound : 0.0;
+    const int oc = run_trial(seed_lo, seed_hi, gsite, sweep, node, k, t, u, a0, end, T, r0, r1, nb, nb,
+                             trunc, room, dst, stride, max_store, start_time, nj_out);
     if (oc != TRIAL_FAIL) { t_out = t; return oc; }
     ++t;
   }
@@ -611,21 +634,25 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
 #define EPV_COOP_WINDOW 4u   /* consecutive trials one helper lane scans per round */
 #endif
 
-__global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
+#ifndef EPV_JUMPS_WAVES
+#define EPV_JUMPS_WAVES 3   /* waves per SIMD the register allocation aims for (<= 168 VGPRs) */
+#endif
+__global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
                                                            uint32_t seed_hi, uint32_t sweep,
                                                            uint32_t tasks_per_wave, uint64_t s0,
                                                            double indep_r0, double indep_r1,
                                                            unsigned long long *counters) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   // per-wave cooperative-search area: task slots by rank and per-lane trial results
-  __shared__ double c_len_[4][64], c_r0_[4][64], c_r1_[4][64], c_tj_[4][64 * EPV_TJ];
+  __shared__ double c_len_[4][64], c_r0_[4][64], c_r1_[4][64], c_trunc_[4][64], c_tj_[4][64 * EPV_TJ];
   __shared__ uint32_t c_misc_[4][64], c_gsite_[4][64], c_tbase_[4][64], c_nk_[4][64], c_res_[4][64],
       c_tw_[4][64];
   stage_constants(S, s_mem);
   const double *s_rates = s_mem, *s_blen = s_mem + 20;
   const uint32_t wave = threadIdx.x >> 6;
   const int lane = epv_lane();
-  double *c_len = c_len_[wave], *c_r0 = c_r0_[wave], *c_r1 = c_r1_[wave], *c_tj = c_tj_[wave];
+  double *c_len = c_len_[wave], *c_r0 = c_r0_[wave], *c_r1 = c_r1_[wave], *c_trunc = c_trunc_[wave],
+         *c_tj = c_tj_[wave];
   uint32_t *c_misc = c_misc_[wave], *c_gsite = c_gsite_[wave], *c_tbase = c_tbase_[wave],
            *c_nk = c_nk_[wave], *c_res = c_res_[wave], *c_tw = c_tw_[wave];
   const bool indep = indep_r0 > 0.0;   // epv_indep_update_paths: rates are not context dependent
@@ -683,7 +710,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
     while (__any(active)) {
       bool pend = false, last = false, take_left = false;
       uint32_t sampled = 0, tbase = EPV_INLINE_TRIALS + 1u;
-      double len = 0.0, r0 = 1.0, r1 = 1.0, seg_end = 0.0;
+      double len = 0.0, r0 = 1.0, r1 = 1.0, seg_end = 0.0, trunc = 0.0;
       if (active) {
         last = !(i < L.nj || j < R.nj);
         take_left = tl < tr;
@@ -692,10 +719,12 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
         sampled = (uint32_t)(word >> (k & 63u)) & 1u;
         r0 = indep ? indep_r0 : s_rates[trip0];
         r1 = indep ? indep_r1 : s_rates[trip0 | 2u];
+        // sample_trunc_exp's 1 - exp(-rate_a T) (EndCondSampling.cpp:577-580), state changes only
+        if (sampled != prev) trunc = 1.0 - epv_exp(-(prev ? r1 : r0) * len);
         if (!ovf) {
           uint32_t njt, tw;
           const int oc = scan_trials(seed_lo, seed_hi, gsite, sweep, node, k, 1u, EPV_INLINE_TRIALS, prev,
-                                     sampled, len, r0, r1, C - cnt, dst + (uint64_t)cnt * n, n,
+                                     sampled, len, r0, r1, trunc, C - cnt, dst + (uint64_t)cnt * n, n,
                                      0xffffffffu, time_passed, tw, njt);
           if (oc == TRIAL_OK) cnt += njt;
           else if (oc == TRIAL_OVERFLOW) ovf = true;
@@ -717,7 +746,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
         const uint32_t G = 1u << lg;
         const uint32_t rank = (uint32_t)__popcll(todo & ((1ull << lane) - 1ull));
         if (pend) {
-          c_len[rank] = len; c_r0[rank] = r0; c_r1[rank] = r1;
+          c_len[rank] = len; c_r0[rank] = r0; c_r1[rank] = r1; c_trunc[rank] = trunc;
           c_misc[rank] = prev | (sampled << 1) | ((C - cnt) << 8);
           c_gsite[rank] = gsite;
           c_tbase[rank] = tbase;
@@ -729,11 +758,11 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
         int oc = TRIAL_FAIL;
         if (tj < P) {
           const uint32_t misc = c_misc[tj], nk = c_nk[tj];
-          const double t_len = c_len[tj], t_r0 = c_r0[tj], t_r1 = c_r1[tj];
+          const double t_len = c_len[tj], t_r0 = c_r0[tj], t_r1 = c_r1[tj], t_trunc = c_trunc[tj];
           const uint32_t t0 = c_tbase[tj] + tr_ * EPV_COOP_WINDOW, t_site = c_gsite[tj];
           uint32_t njt, tw = 0u;
           oc = scan_trials(seed_lo, seed_hi, t_site, sweep, nk >> 12, nk & 4095u, t0, EPV_COOP_WINDOW,
-                           misc & 1u, (misc >> 1) & 1u, t_len, t_r0, t_r1, misc >> 8,
+                           misc & 1u, (misc >> 1) & 1u, t_len, t_r0, t_r1, t_trunc, misc >> 8,
                            c_tj + (size_t)lane * EPV_TJ, 1u, EPV_TJ, 0.0, tw, njt);
           c_tw[lane] = tw;
           c_res[lane] = (uint32_t)oc | (njt << 8);
@@ -759,7 +788,7 @@ __global__ __launch_bounds__(256) void epv_mh_jumps_kernel(EpvDev S, uint32_t se
                                                       EPV_FIRST_DRAW_BLOCK);
                 uint32_t nj2;
                 run_trial(seed_lo, seed_hi, gsite, sweep, node, k, tw, (tw & 1u) ? fb.d1 : fb.d0, prev,
-                          sampled, len, r0, r1, 0.0, 0.0, C - cnt, d2, n, 0xffffffffu, time_passed, nj2);
+                          sampled, len, r0, r1, 0.0, 0.0, trunc, C - cnt, d2, n, 0xffffffffu, time_passed, nj2);
               }
               cnt += njt;
             } else {

@@ -53,6 +53,16 @@ enum { ORC_RNG_MT = 0, ORC_RNG_PHILOX = 1 };
 enum { ORC_MATH_LIBM = 0, ORC_MATH_EPV = 1 };
 enum { ORC_SCHED_SEQ = 0, ORC_SCHED_3COLOUR = 1 };
 enum { ORC_REDUCE_SEQ = 0, ORC_REDUCE_TREE = 1 };
+/* end-conditioned sampler of a segment whose end state differs from its start state:
+ *   FORWARD  plain forward rejection, what the reference's hot path calls
+ *            (EndCondSampling.cpp:479-509) -- needs ~1/P(a->b) trials, hundreds to 1e5 on a
+ *            short branch;
+ *   NIELSEN  the reference's own end_cond_sampling_Nielsen (EndCondSampling.cpp:576-617):
+ *            first jump from the truncated exponential, then forward sampling; the same
+ *            conditional law, but the acceptance probability no longer vanishes with the
+ *            segment length.  The parallel rung and the GPU use this one.
+ * Segments that keep their state use forward rejection in both (as Nielsen's routine does). */
+enum { ORC_SAMPLER_FORWARD = 0, ORC_SAMPLER_NIELSEN = 1 };
 
 typedef struct {
   uint8_t init;
@@ -84,7 +94,7 @@ typedef struct orc_state {
   double rates[8], log_rates[8], T[4];
   orc_path *paths;
   double *tri_llh;
-  int rng_mode, math_mode, schedule, reduce_mode;
+  int rng_mode, math_mode, schedule, reduce_mode, sampler_mode;
   uint32_t cap; /* max jumps per (site,branch) path; 0 = unbounded */
   orc_mt19937 mt;
   uint64_t seed;
@@ -267,17 +277,41 @@ static int forward_rejection(orc_state *st, orc_scratch *sc, orc_rng *g,
                              orc_path *out) {
   const uint32_t cap = st->cap;
   const uint32_t room = cap ? cap - out->n : 0xffffffffu; /* jumps still storable */
+  const int nielsen = st->sampler_mode == ORC_SAMPLER_NIELSEN && start != end;
+  /* sample_trunc_exp (EndCondSampling.cpp:577-580): 1 - exp(-lambda T), the same every trial */
+  const double rate_a = start ? rate1 : rate0;
+  const double trunc = nielsen ? 1.0 - st->fexp(-rate_a * T) : 0.0;
   uint32_t t = 1;
   for (;;) {
     rng_trial_begin(g, b, k, t);
     uint32_t nj = 0;
     int a = start;
     double tau = 0.0;
-    int overflow = 0;
+    int overflow = 0, bad = 0;
 #ifndef _OPENMP
     ++st->n_trials;
 #endif
-    for (;;) {
+    if (nielsen) {
+      /* EndCondSampling.cpp:606-610: the first jump, then the other state */
+      const double u = rng_trial_canonical(g);
+#ifndef _OPENMP
+      ++st->n_draws;
+#endif
+      tau = -st->flog(1.0 - u * trunc) / rate_a;
+      /* mathematically tau < T; a draw within rounding of 1 could land on T: redraw (the
+       * reference has no such guard; the event has probability ~1e-13 per draw) */
+      if (!(tau < T)) bad = 1;
+      else if (cap && nj >= room) overflow = 1;
+      else {
+        a ^= 1;
+        if (nj >= sc->trial_cap) {
+          sc->trial_cap = sc->trial_cap ? sc->trial_cap * 2 : 16;
+          sc->trial = (double *)realloc(sc->trial, sc->trial_cap * sizeof(double));
+        }
+        sc->trial[nj++] = tau;
+      }
+    }
+    while (!bad && !overflow) {
       const double u = rng_trial_canonical(g);
 #ifndef _OPENMP
       ++st->n_draws;
@@ -293,7 +327,7 @@ static int forward_rejection(orc_state *st, orc_scratch *sc, orc_rng *g,
       sc->trial[nj++] = tau;
     }
     if (overflow) return 1;
-    if (a == end) {
+    if (!bad && a == end) {
       for (uint32_t i = 0; i < nj; ++i) path_push(out, sc->trial[i] + start_time);
       return 0;
     }
@@ -552,8 +586,12 @@ ORC_API void orc_set_modes(orc_state *st, int rng_mode, int math_mode, int sched
                            int reduce_mode, uint32_t cap) {
   st->rng_mode = rng_mode; st->math_mode = math_mode; st->schedule = schedule;
   st->reduce_mode = reduce_mode; st->cap = cap;
+  /* default pairing: the reference-schedule rung keeps the reference's forward rejection,
+   * the parallel (Philox) rung uses the Nielsen sampler the GPU implements */
+  st->sampler_mode = rng_mode == ORC_RNG_PHILOX ? ORC_SAMPLER_NIELSEN : ORC_SAMPLER_FORWARD;
   set_math(st);
 }
+ORC_API void orc_set_sampler(orc_state *st, int sampler_mode) { st->sampler_mode = sampler_mode; }
 ORC_API void orc_seed_mt(orc_state *st, uint64_t seed) { orc_mt_seed(&st->mt, (uint32_t)seed); }
 ORC_API void orc_seed_philox(orc_state *st, uint64_t seed) { st->seed = seed; }
 ORC_API void orc_set_model(orc_state *st, const double *rates, const double *T) {
@@ -966,6 +1004,7 @@ ORC_API uint64_t orc_init_paths_indep(int rng_mode, int math_mode, uint64_t seed
   orc_state st;
   memset(&st, 0, sizeof(st));
   st.rng_mode = rng_mode; st.math_mode = math_mode; st.seed = seed; st.cap = 0;
+  st.sampler_mode = rng_mode == ORC_RNG_PHILOX ? ORC_SAMPLER_NIELSEN : ORC_SAMPLER_FORWARD;
   set_math(&st);
   orc_mt_seed(&st.mt, (uint32_t)seed);
   orc_scratch sc;
@@ -1085,7 +1124,10 @@ ORC_API void orc_kat_end_cond_means(int rng_mode, int math_mode, uint64_t seed, 
                                     double r1, int a, int b, double T, uint64_t n, double *out) {
   orc_state st;
   memset(&st, 0, sizeof(st));
-  st.rng_mode = rng_mode; st.math_mode = math_mode; st.seed = seed; st.cap = 0;
+  st.rng_mode = rng_mode & 0xff; st.math_mode = math_mode; st.seed = seed; st.cap = 0;
+  /* bit 8 of rng_mode selects the sampler explicitly: 0x100 forward, 0x200 Nielsen */
+  st.sampler_mode = (rng_mode & 0x200) ? ORC_SAMPLER_NIELSEN : (rng_mode & 0x100) ? ORC_SAMPLER_FORWARD
+                    : (st.rng_mode == ORC_RNG_PHILOX ? ORC_SAMPLER_NIELSEN : ORC_SAMPLER_FORWARD);
   set_math(&st);
   orc_mt_seed(&st.mt, (uint32_t)seed);
   orc_scratch sc;
@@ -1108,6 +1150,37 @@ ORC_API void orc_kat_end_cond_means(int rng_mode, int math_mode, uint64_t seed, 
   }
   out[0] = j01 / (double)n; out[1] = j10 / (double)n; out[2] = d0 / (double)n;
   free(p.t); free(sc.trial);
+}
+
+/* the raw paths of the same sampler: n consecutive samples (one mt19937 stream in MT mode,
+ * Philox site index i otherwise); counts[i] jumps each, times concatenated (up to cap).
+ * rng_mode carries the sampler bits described above.  Returns the total number of jumps. */
+ORC_API uint64_t orc_kat_end_cond_paths(int rng_mode, int math_mode, uint64_t seed, double r0, double r1,
+                                        int a, int b, double T, uint64_t n, uint32_t *counts,
+                                        double *times, uint64_t cap) {
+  orc_state st;
+  memset(&st, 0, sizeof(st));
+  st.rng_mode = rng_mode & 0xff; st.math_mode = math_mode; st.seed = seed; st.cap = 0;
+  st.sampler_mode = (rng_mode & 0x200) ? ORC_SAMPLER_NIELSEN : (rng_mode & 0x100) ? ORC_SAMPLER_FORWARD
+                    : (st.rng_mode == ORC_RNG_PHILOX ? ORC_SAMPLER_NIELSEN : ORC_SAMPLER_FORWARD);
+  set_math(&st);
+  orc_mt_seed(&st.mt, (uint32_t)seed);
+  orc_scratch sc;
+  memset(&sc, 0, sizeof(sc));
+  orc_path p;
+  memset(&p, 0, sizeof(p));
+  uint64_t tot = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    orc_rng g;
+    g.st = &st; g.site = (uint32_t)i; g.sweep = 0;
+    p.n = 0;
+    forward_rejection(&st, &sc, &g, 1, 0, r0, r1, a, b, T, 0.0, &p);
+    counts[i] = p.n;
+    for (uint32_t k = 0; k < p.n; ++k, ++tot)
+      if (tot < cap) times[tot] = p.t[k];
+  }
+  free(p.t); free(sc.trial);
+  return tot;
 }
 
 ORC_API double orc_kat_exp(double x) { return orc_exp(x); }

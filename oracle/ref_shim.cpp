@@ -261,6 +261,25 @@ uint64_t ref_init_paths_indep(uint64_t seed, const double *rates, uint64_t n, co
   return tot;
 }
 
+/* the LINKED end_cond_sampling_Nielsen (EndCondSampling.cpp:583-617) and, for sampler = 0,
+ * end_cond_sample_forward_rejection(ctmm, ...) (:512-542): n consecutive samples a -> b on
+ * [0, T] from one std::mt19937(seed) */
+uint64_t ref_kat_end_cond_paths(int sampler, uint64_t seed, double r0, double r1, int a, int b, double T,
+                                uint64_t n, uint32_t *counts, double *times, uint64_t cap) {
+  std::mt19937 gen(seed);
+  const TwoStateCTMarkovModel ctmm(r0, r1);
+  uint64_t tot = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    vector<double> jt;
+    if (sampler == 1) end_cond_sampling_Nielsen(ctmm, a, b, T, gen, jt, 0.0);
+    else end_cond_sample_forward_rejection(ctmm, a, b, T, gen, jt, 0.0);
+    counts[i] = (uint32_t)jt.size();
+    for (size_t k = 0; k < jt.size(); ++k, ++tot)
+      if (tot < cap) times[tot] = jt[k];
+  }
+  return tot;
+}
+
 /* ---- site-independent model: the linked IndepSite.cpp */
 void ref_indep_expectation(void *h, const double *rates, double *J, double *D) {
   RefState *st = static_cast<RefState *>(h);

@@ -156,6 +156,21 @@ def kat():
                                 orc._p(tt, dbl), orc._p(pp, C.c_uint64), cap)
         out["fwd_%s_seqs" % cfg], out["fwd_%s_off" % cfg] = seqs, off
         out["fwd_%s_t" % cfg], out["fwd_%s_p" % cfg] = tt[:tot], pp[:tot]
+    # the LINKED end-conditioned samplers alone: forward rejection (the hot path's) and
+    # end_cond_sampling_Nielsen (the one the parallel rung / the GPU use for state changes)
+    L.ref_kat_end_cond_paths.restype = C.c_uint64
+    L.ref_kat_end_cond_paths.argtypes = [C.c_int, C.c_uint64, dbl, dbl, C.c_int, C.c_int, dbl, C.c_uint64,
+                                         u32p, dp, C.c_uint64]
+    ec = [(0.236, 10.2, 0, 1, 0.05), (3.65, 4.19, 1, 0, 0.3), (0.0869, 3.45, 1, 1, 1.0),
+          (10.2, 0.236, 0, 1, 2.0), (3.65, 3.45, 0, 0, 0.02), (0.0869, 0.236, 1, 0, 0.001)]
+    out["ec_grid"] = np.array(ec)
+    for sampler in (0, 1):
+        for i, (r0, r1, a, b, T) in enumerate(ec):
+            n, cap = 200, 50000
+            cnt, tt = np.zeros(n, np.uint32), np.zeros(cap)
+            tot = L.ref_kat_end_cond_paths(sampler, 7, r0, r1, a, b, T, n, orc._p(cnt, C.c_uint32),
+                                           orc._p(tt, dbl), cap)
+            out["ec%d_%d_counts" % (sampler, i)], out["ec%d_%d_times" % (sampler, i)] = cnt, tt[:tot]
     np.savez_compressed(os.path.join(HERE, "kat.npz"), **out)
     print("wrote kat")
 

@@ -14,6 +14,7 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libepievo_ref.so")
 
 RNG_MT, RNG_PHILOX = 0, 1
 MATH_LIBM, MATH_EPV = 0, 1
+SAMPLER_FORWARD, SAMPLER_NIELSEN = 0, 1
 SCHED_SEQ, SCHED_3COLOUR = 0, 1
 REDUCE_SEQ, REDUCE_TREE = 0, 1
 
@@ -78,6 +79,10 @@ def orc_lib():
         L.orc_indep_update_paths.argtypes = [C.c_void_p, dp, C.c_uint32]
         L.orc_exact_posterior.argtypes = [dp, C.c_uint64, u8p, u8p, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, dp, dp, dp, dp]
         L.orc_exact_posterior.restype = C.c_uint64
+        L.orc_kat_end_cond_paths.restype = C.c_uint64
+        L.orc_kat_end_cond_paths.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_int,
+                                             C.c_double, C.c_uint64, C.POINTER(C.c_uint32), dp, C.c_uint64]
+        L.orc_set_sampler.argtypes = [C.c_void_p, C.c_int]
         L.orc_kat_exp.argtypes = [C.c_double]
         L.orc_kat_exp.restype = C.c_double
         L.orc_kat_log.argtypes = [C.c_double]

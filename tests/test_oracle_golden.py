@@ -126,3 +126,20 @@ def test_init_paths_indep_rung_a_vs_linked_reference(n, seed):
     a = orc.init_paths_indep("orc", seed, model.rates, root, leaf, 1.0, "A")
     r = orc.init_paths_indep("ref", seed, model.rates, root, leaf, 1.0)
     assert orc.paths_equal(a, r)
+
+
+def test_end_cond_samplers_match_linked_reference():
+    """forward rejection (EndCondSampling.cpp:512-542) and end_cond_sampling_Nielsen (:583-617):
+    the oracle's restatement with mt19937 + glibc gives the linked functions' jump times
+    bit-for-bit over 200 consecutive samples of each grid point"""
+    import ctypes as C
+    g = np.load(os.path.join(GOLDEN, "kat.npz"))
+    L = orc.orc_lib()
+    for sampler, bits in ((0, 0x100), (1, 0x200)):
+        for i, (r0, r1, a, b, T) in enumerate(g["ec_grid"]):
+            want_c, want_t = g["ec%d_%d_counts" % (sampler, i)], g["ec%d_%d_times" % (sampler, i)]
+            cnt, tt = np.zeros(len(want_c), np.uint32), np.zeros(max(len(want_t), 1))
+            tot = L.orc_kat_end_cond_paths(orc.RNG_MT | bits, orc.MATH_LIBM, 7, r0, r1, int(a), int(b), T,
+                                           len(want_c), orc._p(cnt, C.c_uint32), orc._p(tt, C.c_double), len(tt))
+            assert tot == len(want_t) and np.array_equal(cnt, want_c)
+            assert np.array_equal(tt[:tot], want_t)

@@ -15,7 +15,9 @@ from common import GOLDEN, simulate
 def test_end_conditioned_sampler_means_match_reference_closed_forms():
     """expectation_J / expectation_D of the reference (ContinuousTimeMarkovModel.cpp:168-226,
     values stored in golden/kat.npz) are the exact means of ANY correct end-conditioned
-    sampler; check the forward-rejection sampler under both random sources."""
+    sampler; check forward rejection (the reference's hot path, rung A) and the Nielsen
+    sampler the parallel rung and the GPU use for state changes (EndCondSampling.cpp:583-617),
+    the latter also where forward rejection needs ~1/(r T) trials per sample."""
     g = np.load(os.path.join(GOLDEN, "kat.npz"))
     L = orc.orc_lib()
     n = 40000
@@ -23,9 +25,10 @@ def test_end_conditioned_sampler_means_match_reference_closed_forms():
         J0, J1, D0 = e[0:4].reshape(2, 2), e[4:8].reshape(2, 2), e[8:12].reshape(2, 2)
         for a in (0, 1):
             for b in (0, 1):
-                if a != b and min(r0, r1) * T < 0.02:
-                    continue          # ~1/(r T) trials per sample: keep the CPU suite quick
-                for rng, math in ((orc.RNG_PHILOX, orc.MATH_EPV), (orc.RNG_MT, orc.MATH_LIBM)):
+                for rng, math in ((orc.RNG_PHILOX, orc.MATH_EPV), (orc.RNG_MT, orc.MATH_LIBM),
+                                  (orc.RNG_MT | 0x200, orc.MATH_LIBM)):
+                    if rng == orc.RNG_MT and a != b and min(r0, r1) * T < 0.02:
+                        continue      # forward rejection: ~1/(r T) trials per sample, keep the suite quick
                     out = np.zeros(3)
                     L.orc_kat_end_cond_means(rng, math, 5, r0, r1, a, b, T, n, orc._p(out, C.c_double))
                     exp = np.array([J0[a, b], J1[a, b], D0[a, b]])
