@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
           const uint32_t start_state = (par == 0u) ? root_state : (regA[par * 64u + lane] >> 31);
           const PathRef cur = path_ref(S, selM, b, site);
           uint32_t prev = start_state;
-          bool clean = true, flips = false;
+          bool clean = true;
           unsigned long long word = 0ull;
           uint64_t *states = S.prop_states + ((uint64_t)b * S.phase_cap + tid) * S.W;
           // forward merge of the neighbours' jumps (Segment.cpp:35-79)
@@ -531,7 +531,6 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
             // trial 1's first draw is the other half of the same Philox block
             clean = clean && (sampled == prev) &&
                     (1.0 - sblk.d1 < nojump_bound(len * (prev ? r1 : r0)));
-            flips = flips || (sampled != prev);
             word |= (unsigned long long)sampled << (k & 63u);
             if ((k & 63u) == 63u) { states[k >> 6] = word; word = 0ull; }
 #ifndef EPV_ABLATE_CURPATH
@@ -565,12 +564,7 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
           orig_proposal += lp;
           if (!clean) {
             dirty |= 1ull << (b & 63u);
-#ifndef EPV_TASK_KEY
-#define EPV_TASK_KEY 0
-#endif
-            const bool back = EPV_TASK_KEY == 0 ? (K > 1u) : EPV_TASK_KEY == 1 ? flips
-                              : EPV_TASK_KEY == 2 ? (flips || K > 1u) : false;
-            if (back) multi |= 1ull << (b & 63u);
+            if (K > 1u) multi |= 1ull << (b & 63u);
           }
         }
         // flush the dirty (site, branch) pairs of the last <= 64 branches: ONE atomic per
