@@ -171,7 +171,8 @@ def main():
     kbar = len(fp_own.jumps) / float(n_local * (tree.n_nodes - 1))
 
     ss = ShardedSampler(comm, device=local_rank)
-    ss.setup(model, tree, fp_own, n_global, capacity=16)
+    # 16 jump slots per (site, branch) on the short trees; the T = 1 branch picks its own
+    ss.setup(model, tree, fp_own, n_global, capacity=16 if args.config != "pair" else 0)
     ss.dev.set_timing(False)
 
     def barrier():

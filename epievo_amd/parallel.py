@@ -104,6 +104,11 @@ class ShardedSampler:
             from .sampler import DeviceSampler
             device_factory = DeviceSampler
         self.dev = device_factory(device)
+        # a capacity overflow widens this shard's jump slots and the run carries on (as the
+        # reference's vectors would); refresh_halos() brings all shards to the same width
+        # before columns travel
+        if hasattr(self.dev, "auto_grow"):
+            self.dev.auto_grow = True
         self.halo = 0
 
     def owned_sites(self):
@@ -142,6 +147,11 @@ class ShardedSampler:
         """ship my H outermost owned columns to each neighbour; take theirs as my halos"""
         if self.comm.world == 1:
             return
+        if hasattr(self.dev, "capacity"):
+            # packed columns have capacity-dependent size: agree on the widest
+            caps = [int(x[0]) for x in self.comm.allgather(np.array([float(self.dev.capacity())]))]
+            if max(caps) != self.dev.capacity():
+                self.dev.set_capacity(max(caps))
         H = self.halo
         to_left = self.dev.get_columns(self.left, H) if self.left else None
         to_right = self.dev.get_columns(self.n_loc - self.right - H, H) if self.right else None

@@ -12,6 +12,7 @@
  *   pruning / pruning_branch / process_branch_above   src/libepievo/SingleSiteSampler.cpp:80-157
  *   downward_sampling(_branch)                        ...:180-255
  *   forward_sampling / end_cond_sample_forward_rejection  src/libepievo/EndCondSampling.cpp:466-509
+ *   sample_trunc_exp / end_cond_sampling_Nielsen          ...:576-617 (parallel rung, state changes)
  *   proposal_prob(_branch)                            SingleSiteSampler.cpp:272-339
  *   path_log_likelihood / root_prior_lh / log_likelihood  ...:263-269,342-391
  *   add_sufficient_statistics                         src/libepievo/Path.cpp:206-301
@@ -27,10 +28,13 @@
  *           the golden fixtures in tests/golden/.
  *   rung B  parallel-schedule: 3-colour sweep, random-access Philox4x32-10,
  *           orc_exp/orc_log, canonical binary-tree J/D reduction, bounded
- *           jump capacity.  This is the contract the gfx950 kernels match
- *           bit-for-bit.
+ *           jump capacity, and the reference's Nielsen sampler instead of
+ *           forward rejection for segments that change state (see
+ *           ORC_SAMPLER_* below; pinned against the linked function too).
+ *           This is the contract the gfx950 kernels match bit-for-bit.
  * Both rungs run the SAME per-site function below; only the random source,
- * the exp/log pair, the visiting order and the reduction order differ.
+ * the exp/log pair, the visiting order, the reduction order and that sampler
+ * choice differ.
  *
  * Path storage: node-major flat arrays, index (node*n_sites + site), node 0
  * (the root) unused -- as in the reference, where paths[site][0] is a dummy.
