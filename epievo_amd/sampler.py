@@ -49,7 +49,8 @@ def lib():
     """Load the HIP library; raise (never fall back) when it has not been built."""
     global _lib
     if _lib is None:
-        path = _build.HIP_SO
+        # EPIEVO_MI355X_LIB: another build of the same library (A/B runs of kernel variants)
+        path = os.environ.get("EPIEVO_MI355X_LIB", _build.HIP_SO)
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; "
                                "g.build()'` (hipcc --offload-arch=gfx950)" % path)
