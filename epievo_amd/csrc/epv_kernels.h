@@ -85,10 +85,9 @@ __device__ __forceinline__ double wave_tree_sum16(const double v[16], int lane, 
 }
 
 // ------------------------------------------------------------------ path access
-// meta is SITE-major: the B bytes of one site's column sit together, so the branches of a
-// column come out of one cache line (one dword for tree.nwk's four branches)
+// meta layout, see epv_device.h (branch-major by default)
 __device__ __forceinline__ uint64_t meta_idx(const EpvDev &S, uint32_t buf, uint32_t b, uint64_t site) {
-  return ((uint64_t)buf * S.n + site) * S.B + b;
+  return S.meta_bm ? ((uint64_t)buf * S.B + b) * S.n + site : ((uint64_t)buf * S.n + site) * S.B + b;
 }
 struct PathRef {
   const double *j;  // jump k lives at j[k * n]
