@@ -115,9 +115,10 @@ int plan_mh(epv_ctx *c) {
     c->mh_lds = fixed + (size_t)pool * 16u;
     return EPV_OK;
   }
-  const uint64_t pool = std::max<uint64_t>(worst, 2u * typical);
+  // global slab: `worst` ROWS of 64 interleaved records per wave (a lane can always run)
+  const uint64_t pool = worst;
   const uint64_t blocks = (c->S.phase_cap + 63u) / 64u;
-  const uint64_t need = blocks * pool * 2u;
+  const uint64_t need = blocks * pool * 128u;
   if (need > c->gpool_cap) {
     dfree(c->d_gpool);
     c->gpool_cap = 0;

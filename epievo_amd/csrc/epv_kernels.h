@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
   const uint32_t regA_dbl = (S.N * 64u + 1u) / 2u;   // N * 64 u32
   const uint32_t wave_dbl = ((regA_dbl + 1u) & ~1u) + (GPOOL ? 0u : pool_entries * 2u);
   uint32_t *regA = reinterpret_cast<uint32_t *>(s_mem + const_dbl + (size_t)wave * wave_dbl);
-  double *pool = GPOOL ? gpool + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * pool_entries * 2u
+  double *pool = GPOOL ? gpool + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * pool_entries * 128u
                        : s_mem + const_dbl + (size_t)wave * wave_dbl + ((regA_dbl + 1u) & ~1u);
   stage_constants(S, s_const);
   const double *s_rates = s_const;
@@ -412,8 +412,12 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
   while (__any(pending)) {
     const uint32_t want = pending ? need : 0u;
     const uint32_t incl = wave_incl_scan_u32(want);
-    const bool run = pending && incl <= pool_entries;
-    double *my = pool + (size_t)(incl - want) * 2u;  // this lane's records
+    // LDS pool: the lanes' record ranges are packed by the prefix sum.  Global slab: records
+    // are INTERLEAVED -- record r of lane l at (r * 64 + l) -- so that a wave-wide access is
+    // one contiguous KB instead of 64 cache lines; a lane then needs `need` rows of its own
+    constexpr size_t RS = GPOOL ? 128u : 2u;   // doubles between consecutive records of a lane
+    const bool run = pending && (GPOOL ? need <= pool_entries : incl <= pool_entries);
+    double *my = GPOOL ? pool + (size_t)lane * 2u : pool + (size_t)(incl - want) * 2u;
 
     // ---- 1. pruning, reverse pre-order (SingleSiteSampler.cpp:116-157) over segments
     //         re-derived backwards from the neighbours' jumps (Segment.cpp:35-79: on a
@@ -435,12 +439,12 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
           q1 = leaf_state ? 1.0 : 0.0;
         } else {
           for (uint32_t ch = 1u; ch < sub; ch += S.subtree[node + ch]) {
-            const double *a = my + (size_t)(regA[(node + ch) * 64u + lane] & 0x7fffffffu) * 2u;
+            const double *a = my + (size_t)(regA[(node + ch) * 64u + lane] & 0x7fffffffu) * RS;
             q0 *= a[0];   // p.front() of the child's branch
             q1 *= a[1];
           }
         }
-        double *recq = my + (size_t)(off + K) * 2u;
+        double *recq = my + (size_t)(off + K) * RS;
         recq[0] = q0; recq[1] = q1;
         regA[node * 64u + lane] = off;
         double n0 = q0, n1 = q1;
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
           const double P10 = 1.0 - P11;
           const double a = P00 * n0 + P01 * n1;
           const double c = P10 * n0 + P11 * n1;
-          double *rec = my + (size_t)(off + kk) * 2u;
+          double *rec = my + (size_t)(off + kk) * RS;
           rec[0] = a; rec[1] = c;
           n0 = a; n1 = c;
           if (kk > 0u) {
@@ -509,14 +513,14 @@ __global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
           uint32_t cs_start = cur.init, cs_end = cur.init, sj = 0, ej = 0;
           double end_time = 0.0, lp = 0.0;
           double cur_next = cur.nj ? cur.j[0] : EPV_INF;
-          double pk0 = my[(size_t)off * 2u], pk1 = my[(size_t)off * 2u + 1u];
+          double pk0 = my[(size_t)off * RS], pk1 = my[(size_t)off * RS + 1u];
           for (uint32_t k = 0; k < K; ++k) {
             const bool last = (k + 1u == K);
             const bool take_left = tl < tr;
             const double seg_end = last ? s_blen[node] : (take_left ? tl : tr);
             const double len = seg_end - seg_start;
-            const double nxt0 = my[(size_t)(off + k + 1u) * 2u];      // p[k+1][0], or q[0]
-            const double nxt1 = my[(size_t)(off + k + 1u) * 2u + 1u];
+            const double nxt0 = my[(size_t)(off + k + 1u) * RS];      // p[k+1][0], or q[0]
+            const double nxt1 = my[(size_t)(off + k + 1u) * RS + 1u];
             const double r0 = s_rates[trip0], r1 = s_rates[trip0 | 2u];
             const double h = epv_exp(-len * (r0 + r1));
             const double denom = r0 + r1;
