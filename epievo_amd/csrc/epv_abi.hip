@@ -389,9 +389,6 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   c->S.g0 = global_site_offset;
   c->S.n_global = global_site_offset + n_sites;
   c->S.C = capacity;
-  // meta layout (epv_device.h); EPV_META_LAYOUT=site|branch overrides for A/B runs
-  c->S.meta_bm = 1u;   // branch-major measured never slower (tree.nwk: equal; 30 branches: -33 %)
-  if (const char *e = std::getenv("EPV_META_LAYOUT")) c->S.meta_bm = (e[0] == 'b') ? 1u : 0u;
   c->kbar = E ? (double)offsets[E] / (double)E : 0.0;
   HIP_TRY(c, hipMalloc(&c->S.meta, 2u * E));
   HIP_TRY(c, hipMalloc(&c->S.jumps, 2u * E * capacity * sizeof(double)));
@@ -458,8 +455,7 @@ EPV_API int epv_set_capacity(epv_ctx *c, uint32_t capacity) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (uint64_t s = 0; s < n; ++s)
       for (uint64_t b = 0; b < B; ++b)
-        if ((meta[c->S.meta_bm ? ((uint64_t)sel[s] * B + b) * n + s : ((uint64_t)sel[s] * n + s) * B + b] & 127u) >
-            capacity)
+        if ((meta[((uint64_t)sel[s] * B + b) * n + s] & 127u) > capacity)
           return fail(c, EPV_ERR_CAPACITY, "a resident path has more jumps than the requested capacity");
   }
   double *nj = nullptr;

@@ -87,7 +87,7 @@ __device__ __forceinline__ double wave_tree_sum16(const double v[16], int lane, 
 // ------------------------------------------------------------------ path access
 // meta layout, see epv_device.h (branch-major by default)
 __device__ __forceinline__ uint64_t meta_idx(const EpvDev &S, uint32_t buf, uint32_t b, uint64_t site) {
-  return S.meta_bm ? ((uint64_t)buf * S.B + b) * S.n + site : ((uint64_t)buf * S.n + site) * S.B + b;
+  return ((uint64_t)buf * S.B + b) * S.n + site;
 }
 struct PathRef {
   const double *j;  // jump k lives at j[k * n]
