@@ -43,6 +43,8 @@ struct epv_ctx {
   uint64_t partial_cap = 0;
   double *d_jd_acc = nullptr;  // [B*16] accumulated over batch sweeps
   double *d_scale = nullptr;
+  uint8_t *d_stage = nullptr;   // packed-column staging for the halo exchange (grown on demand)
+  uint64_t stage_cap = 0;
   EpvIndepConst *d_indep = nullptr;  // [N] constants of the site-independent model
   // launch shape of the MH kernel
   uint32_t mh_threads = 64, pool_entries = 0;
@@ -79,12 +81,33 @@ void dfree(T *&p) {
   if (p) { (void)hipFree(p); p = nullptr; }
 }
 
+// device scratch that is released on every exit path of an entry point
+template <class T>
+struct DevTmp {
+  T *p = nullptr;
+  DevTmp() = default;
+  DevTmp(const DevTmp &) = delete;
+  DevTmp &operator=(const DevTmp &) = delete;
+  ~DevTmp() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count) { return hipMalloc(&p, count * sizeof(T)); }
+  T *release() { T *q = p; p = nullptr; return q; }
+};
+
 void free_paths(epv_ctx *c) {
   dfree(c->S.meta); dfree(c->S.jumps); dfree(c->S.sel); dfree(c->S.tri);
   dfree(c->S.prop_llr); dfree(c->S.prop_flag); dfree(c->S.prop_states); dfree(c->S.tasks);
   dfree(c->d_partial[0]); dfree(c->d_partial[1]);
   c->partial_cap = 0;
   c->have_paths = c->have_reset = false;
+}
+
+int ensure_stage(epv_ctx *c, uint64_t bytes) {
+  if (bytes <= c->stage_cap) return EPV_OK;
+  dfree(c->d_stage);
+  c->stage_cap = 0;
+  HIP_TRY(c, hipMalloc(&c->d_stage, bytes));
+  c->stage_cap = bytes;
+  return EPV_OK;
 }
 
 size_t const_lds_bytes(uint32_t N) { return (size_t)((20u + N + 1u) & ~1u) * 8u; }
@@ -305,7 +328,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool);
+  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->stream);
@@ -404,21 +427,20 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   HIP_TRY(c, hipMalloc(&c->S.tasks, c->S.task_cap * EPV_SHARDS * sizeof(unsigned long long)));
   HIP_TRY(c, hipMemsetAsync(c->S.meta, 0, 2u * E, c->stream));
   // staging of the CSR form
-  uint8_t *d_init = nullptr;
-  uint64_t *d_off = nullptr;
-  double *d_j = nullptr;
+  DevTmp<uint8_t> d_init;
+  DevTmp<uint64_t> d_off;
+  DevTmp<double> d_j;
   const uint64_t tot = offsets[E];
-  HIP_TRY(c, hipMalloc(&d_init, E));
-  HIP_TRY(c, hipMalloc(&d_off, (E + 1) * sizeof(uint64_t)));
-  HIP_TRY(c, hipMalloc(&d_j, std::max<uint64_t>(tot, 1) * sizeof(double)));
-  HIP_TRY(c, hipMemcpyAsync(d_init, init_state, E, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(d_off, offsets, (E + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  if (tot) HIP_TRY(c, hipMemcpyAsync(d_j, jumps, tot * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, d_init.alloc(E));
+  HIP_TRY(c, d_off.alloc(E + 1));
+  HIP_TRY(c, d_j.alloc(std::max<uint64_t>(tot, 1)));
+  HIP_TRY(c, hipMemcpyAsync(d_init.p, init_state, E, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_off.p, offsets, (E + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  if (tot) HIP_TRY(c, hipMemcpyAsync(d_j.p, jumps, tot * sizeof(double), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(epv_scatter_kernel, dim3((unsigned)((E + 255u) / 256u)), dim3(256), 0, c->stream,
-                     c->S, d_init, d_off, d_j);
+                     c->S, d_init.p, d_off.p, d_j.p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_init); (void)hipFree(d_off); (void)hipFree(d_j);
   c->first = 1;
   c->last = n_sites - 2;
   c->halo_mode = false;
@@ -458,21 +480,21 @@ EPV_API int epv_set_capacity(epv_ctx *c, uint32_t capacity) {
         if ((meta[((uint64_t)sel[s] * B + b) * n + s] & 127u) > capacity)
           return fail(c, EPV_ERR_CAPACITY, "a resident path has more jumps than the requested capacity");
   }
-  double *nj = nullptr;
-  HIP_TRY(c, hipMalloc(&nj, 2u * E * capacity * sizeof(double)));
+  DevTmp<double> nj;
+  HIP_TRY(c, nj.alloc(2u * E * capacity));
   const uint32_t keep = std::min(capacity, c->S.C);
   // plane (buf, b) holds C rows of n doubles: rows 0..keep-1 move to the new stride
   for (uint64_t plane = 0; plane < 2u * B; ++plane)
-    HIP_TRY(c, hipMemcpyAsync(nj + plane * capacity * n, c->S.jumps + plane * c->S.C * n,
+    HIP_TRY(c, hipMemcpyAsync(nj.p + plane * capacity * n, c->S.jumps + plane * c->S.C * n,
                               (size_t)keep * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   const uint32_t W = (2u * capacity + 1u + 63u) / 64u;
-  uint64_t *ns = nullptr;
-  HIP_TRY(c, hipMalloc(&ns, B * c->S.phase_cap * W * sizeof(uint64_t)));
+  DevTmp<uint64_t> ns;
+  HIP_TRY(c, ns.alloc(B * c->S.phase_cap * W));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   (void)hipFree(c->S.jumps);
   (void)hipFree(c->S.prop_states);
-  c->S.jumps = nj;
-  c->S.prop_states = ns;
+  c->S.jumps = nj.release();
+  c->S.prop_states = ns.release();
   c->S.C = capacity;
   c->S.W = W;
   return plan_mh(c);
@@ -490,8 +512,9 @@ EPV_API int epv_init_paths_indep(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
   double dummy = 0.0;
   int rc = epv_upload_paths(c, n_sites, root_states, off.data(), &dummy, capacity ? capacity : 32u, 0);
   if (rc) return rc;
-  uint8_t *d_leaf = nullptr;
-  HIP_TRY(c, hipMalloc(&d_leaf, n_sites));
+  DevTmp<uint8_t> leaf_tmp;
+  HIP_TRY(c, leaf_tmp.alloc(n_sites));
+  uint8_t *d_leaf = leaf_tmp.p;
   HIP_TRY(c, hipMemcpyAsync(d_leaf, leaf_states, n_sites, hipMemcpyHostToDevice, c->stream));
   const uint64_t first = 1, last = n_sites - 2;
   const uint64_t threads = (last - first + 1u + 2u) / 3u;
@@ -514,9 +537,7 @@ EPV_API int epv_init_paths_indep(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
   hipLaunchKernelGGL(epv_init_ends_kernel, dim3(1), dim3(64), 0, c->stream, c->S, d_leaf, (uint32_t)seed,
                      (uint32_t)(seed >> 32), c->blen[1]);
   HIP_TRY(c, hipGetLastError());
-  rc = finish_mcmc(c, nullptr, 0);  // synchronises; reports capacity overflow
-  (void)hipFree(d_leaf);
-  return rc;
+  return finish_mcmc(c, nullptr, 0);  // synchronises (d_leaf is released afterwards); reports overflow
 }
 
 // ---------------------------------------------------------------------------------------
@@ -864,10 +885,12 @@ EPV_API int epv_scale_jump_times(epv_ctx *c, const double *new_branches) {
 static int export_paths(epv_ctx *c, uint8_t *init_state, uint64_t *offsets, double *jumps,
                         uint64_t *total) {
   const uint64_t E = (uint64_t)c->S.B * c->S.n;
-  uint8_t *d_init = nullptr;
-  uint64_t *d_cnt = nullptr;
-  HIP_TRY(c, hipMalloc(&d_init, E));
-  HIP_TRY(c, hipMalloc(&d_cnt, (E + 1) * sizeof(uint64_t)));
+  DevTmp<uint8_t> init_tmp;
+  DevTmp<uint64_t> cnt_tmp;
+  HIP_TRY(c, init_tmp.alloc(E));
+  HIP_TRY(c, cnt_tmp.alloc(E + 1));
+  uint8_t *d_init = init_tmp.p;
+  uint64_t *d_cnt = cnt_tmp.p;
   hipLaunchKernelGGL(epv_count_kernel, dim3((unsigned)((E + 255u) / 256u)), dim3(256), 0, c->stream,
                      c->S, d_init, d_cnt);
   std::vector<uint64_t> off(E + 1);
@@ -881,17 +904,16 @@ static int export_paths(epv_ctx *c, uint8_t *init_state, uint64_t *offsets, doub
     std::memcpy(offsets, off.data(), (E + 1) * sizeof(uint64_t));
     HIP_TRY(c, hipMemcpy(init_state, d_init, E, hipMemcpyDeviceToHost));
     if (run) {
-      double *d_j = nullptr;
-      HIP_TRY(c, hipMalloc(&d_j, run * sizeof(double)));
+      DevTmp<double> j_tmp;
+      HIP_TRY(c, j_tmp.alloc(run));
+      double *d_j = j_tmp.p;
       HIP_TRY(c, hipMemcpyAsync(d_cnt, off.data(), (E + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
       hipLaunchKernelGGL(epv_gather_kernel, dim3((unsigned)((E + 255u) / 256u)), dim3(256), 0,
                          c->stream, c->S, d_cnt, d_j);
       HIP_TRY(c, hipMemcpyAsync(jumps, d_j, run * sizeof(double), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      (void)hipFree(d_j);
     }
   }
-  (void)hipFree(d_init); (void)hipFree(d_cnt);
   return EPV_OK;
 }
 
@@ -930,13 +952,12 @@ EPV_API int epv_get_columns(epv_ctx *c, uint64_t first, uint64_t count, void *pa
   if (count == 0) return EPV_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t bytes = count * epv_column_bytes(c);
-  uint8_t *d = nullptr;
-  HIP_TRY(c, hipMalloc(&d, bytes));
+  if ((rc = ensure_stage(c, bytes))) return rc;
+  uint8_t *d = c->d_stage;
   hipLaunchKernelGGL(epv_pack_columns_kernel, dim3((unsigned)count), dim3(64), 0, c->stream, c->S,
                      first, count, d);
   HIP_TRY(c, hipMemcpyAsync(packed, d, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d);
   return EPV_OK;
 }
 
@@ -947,13 +968,12 @@ EPV_API int epv_put_columns(epv_ctx *c, uint64_t first, uint64_t count, const vo
   if (count == 0) return EPV_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t bytes = count * epv_column_bytes(c);
-  uint8_t *d = nullptr;
-  HIP_TRY(c, hipMalloc(&d, bytes));
+  if ((rc = ensure_stage(c, bytes))) return rc;
+  uint8_t *d = c->d_stage;
   HIP_TRY(c, hipMemcpyAsync(d, packed, bytes, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(epv_unpack_columns_kernel, dim3((unsigned)count), dim3(64), 0, c->stream, c->S,
                      first, count, d);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d);
   return EPV_OK;
 }
 
