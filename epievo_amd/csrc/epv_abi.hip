@@ -155,8 +155,8 @@ int plan_mh(epv_ctx *c) {
   return EPV_OK;
 }
 
-int ensure_partials(epv_ctx *c) {
-  const uint64_t nb = (c->S.n + 255u) / 256u;
+int ensure_partials(epv_ctx *c, uint64_t nb_min = 0) {
+  const uint64_t nb = std::max<uint64_t>((c->S.n + 255u) / 256u, nb_min);
   const uint64_t V = (uint64_t)c->S.B * 16u;
   if (c->partial_cap >= nb * V) return EPV_OK;
   dfree(c->d_partial[0]); dfree(c->d_partial[1]);
@@ -196,7 +196,7 @@ int launch_suffstats(epv_ctx *c, int *which) {
   uint64_t own_lo = 0, own_hi = 0;
   owned_range(c, &own_lo, &own_hi);
   hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)nb, c->S.B), dim3(256), const_lds_bytes(c->S.N),
-                     c->stream, c->S, own_lo, own_hi, c->d_partial[0]);
+                     c->stream, c->S, own_lo, own_hi, (uint64_t)0, c->d_partial[0]);
   uint64_t m = nb;
   int cur = 0;
   while (m > 1) {
@@ -839,6 +839,95 @@ EPV_API int epv_run_mcmc_sums(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint
   return rc;
 }
 
+// ---- several shards on ONE GPU (epievo_amd.parallel.LocalGroup): each shard writes the
+// level-0 block partials of its owned 256-site blocks, per batch sweep, into a buffer shared
+// by the group; one reduction afterwards gives exactly the sums of the unsharded run
+EPV_API int epv_dev_alloc(epv_ctx *c, uint64_t bytes, void **p) {
+  if (!c || !p || !bytes) return EPV_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMalloc(p, bytes));
+  HIP_TRY(c, hipMemset(*p, 0, bytes));
+  return EPV_OK;
+}
+EPV_API int epv_dev_free(epv_ctx *c, void *p) {
+  if (!c) return EPV_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (p) HIP_TRY(c, hipFree(p));
+  return EPV_OK;
+}
+
+EPV_API int epv_run_mcmc_blocks(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint64_t seed,
+                                uint32_t sweep_base, double *d_blocks, uint64_t nb_total,
+                                uint64_t block_offset, uint64_t *n_accepted) {
+  int rc = check_ready(c, true);
+  if (rc) return rc;
+  if (!d_blocks || batch == 0) return fail(c, EPV_ERR_ARG, "bad run_mcmc_blocks arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t V = c->S.B * 16u;
+  uint64_t own_lo = 0, own_hi = 0;
+  owned_range(c, &own_lo, &own_hi);
+  const uint64_t blk_lo = own_lo / 256u, blk_hi = own_hi / 256u;
+  if (block_offset + blk_hi >= nb_total) return fail(c, EPV_ERR_ARG, "owned blocks exceed the group's block buffer");
+  uint32_t sweep = sweep_base;
+  for (uint64_t w = 0; w < burn_in; ++w, ++sweep) {
+    for (int colour = 0; colour < 3; ++colour)
+      if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
+    ++c->n_sweeps;
+  }
+  uint64_t base = 0;
+  if ((rc = current_accepts(c, &base))) return rc;
+  for (uint64_t w = 0; w < batch; ++w, ++sweep) {
+    for (int colour = 0; colour < 3; ++colour)
+      if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
+    ++c->n_sweeps;
+    hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)(blk_hi - blk_lo + 1u), c->S.B), dim3(256),
+                       const_lds_bytes(c->S.N), c->stream, c->S, own_lo, own_hi, blk_lo,
+                       d_blocks + (w * nb_total + block_offset + blk_lo) * V);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return finish_mcmc(c, n_accepted, base);  // synchronises the stream
+}
+
+EPV_API int epv_reduce_blocks(epv_ctx *c, const double *d_blocks, uint64_t nb_total, uint64_t batch,
+                              int average, double *J, double *D) {
+  if (!c || !d_blocks || !J || !D || !nb_total || !batch) return EPV_ERR_ARG;
+  if (!c->have_tree) return fail(c, EPV_ERR_STATE, "epv_set_tree must come first");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_partials(c, nb_total);
+  if (rc) return rc;
+  const uint32_t V = c->S.B * 16u;
+  HIP_TRY(c, hipMemsetAsync(c->d_jd_acc, 0, V * sizeof(double), c->stream));
+  for (uint64_t w = 0; w < batch; ++w) {
+    const double *in = d_blocks + w * nb_total * V;
+    uint64_t m = nb_total;
+    int cur = 1;   // level outputs alternate d_partial[1], d_partial[0], ... as in launch_suffstats
+    if (m == 1) {
+      hipLaunchKernelGGL(epv_accumulate_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream, c->d_jd_acc, in, V);
+      continue;
+    }
+    while (m > 1) {
+      const uint64_t mb = (m + 255u) / 256u;
+      hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb, V / 16u), dim3(256), 0, c->stream, in, m, V,
+                         c->d_partial[cur]);
+      in = c->d_partial[cur];
+      m = mb;
+      cur ^= 1;
+    }
+    hipLaunchKernelGGL(epv_accumulate_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream, c->d_jd_acc, in, V);
+  }
+  HIP_TRY(c, hipGetLastError());
+  std::vector<double> jd(V);
+  HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_jd_acc, V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const double nb = average ? (double)batch : 1.0;
+  for (uint32_t b = 0; b < c->S.B; ++b)
+    for (int k = 0; k < 8; ++k) {
+      J[b * 8 + k] = jd[b * 16 + k] / nb;
+      D[b * 8 + k] = jd[b * 16 + 8 + k] / nb;
+    }
+  return EPV_OK;
+}
+
 EPV_API int epv_run_mcmc(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint64_t seed,
                          uint32_t sweep_base, double *J, double *D, uint64_t *n_accepted) {
   return epv_run_mcmc_sums(c, burn_in, batch, seed, sweep_base, 1, J, D, n_accepted);
@@ -958,6 +1047,31 @@ EPV_API int epv_get_columns(epv_ctx *c, uint64_t first, uint64_t count, void *pa
                      first, count, d);
   HIP_TRY(c, hipMemcpyAsync(packed, d, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EPV_OK;
+}
+
+// columns [src_first, src_first+count) of `src` -> columns [dst_first, ...) of `dst`, both on
+// the same GPU, without leaving it (halo refresh between the shards of a LocalGroup)
+EPV_API int epv_copy_columns(epv_ctx *src, uint64_t src_first, uint64_t count, epv_ctx *dst,
+                             uint64_t dst_first) {
+  int rc = check_ready(src, false);
+  if (rc) return rc;
+  if ((rc = check_ready(dst, false))) return rc;
+  if (src->device != dst->device || src->S.B != dst->S.B || src->S.C != dst->S.C)
+    return fail(dst, EPV_ERR_ARG, "epv_copy_columns needs two contexts of one GPU with equal tree and capacity");
+  if (src_first + count > src->S.n || dst_first + count > dst->S.n) return fail(dst, EPV_ERR_ARG, "bad column range");
+  if (count == 0) return EPV_OK;
+  HIP_TRY(src, hipSetDevice(src->device));
+  const uint64_t bytes = count * epv_column_bytes(src);
+  if ((rc = ensure_stage(src, bytes))) return rc;
+  hipLaunchKernelGGL(epv_pack_columns_kernel, dim3((unsigned)count), dim3(64), 0, src->stream, src->S,
+                     src_first, count, src->d_stage);
+  HIP_TRY(src, hipGetLastError());
+  HIP_TRY(src, hipStreamSynchronize(src->stream));
+  hipLaunchKernelGGL(epv_unpack_columns_kernel, dim3((unsigned)count), dim3(64), 0, dst->stream, dst->S,
+                     dst_first, count, src->d_stage);
+  HIP_TRY(dst, hipGetLastError());
+  HIP_TRY(dst, hipStreamSynchronize(dst->stream));
   return EPV_OK;
 }
 

@@ -1208,7 +1208,8 @@ __global__ __launch_bounds__(256) void epv_reset_kernel(EpvDev S) {
 // =========================================================================
 
 __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t first,
-                                                           uint64_t last, double *partial) {
+                                                           uint64_t last, uint64_t block0,
+                                                           double *partial) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   __shared__ double s_part[4][16];
   stage_constants(S, s_mem);
@@ -1216,7 +1217,8 @@ __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t fi
   const int lane = epv_lane();
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t b = blockIdx.y;          // one branch per block row: B x more blocks in flight
-  const uint64_t site = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // block0: first 256-site block to process (partial[] is relative to it)
+  const uint64_t site = (block0 + blockIdx.x) * blockDim.x + threadIdx.x;
   const bool on = site >= first && site <= last && site >= 1 && site + 1 < S.n;
   Acc8 A;
   acc_clear(A);

@@ -211,3 +211,226 @@ class ShardedSampler:
 
     def owned_paths(self):
         return self.dev.paths().slice_sites(self.left, self.n_loc - self.right)
+
+
+class LocalGroup:
+    """Two or three shards on ONE GPU behind the DeviceSampler interface.
+
+    The three kernels of a colour phase depend on each other, so on one stream every launch
+    pays its own ramp and tail.  Two contexts on the same device, each owning half of the
+    (local) genome plus redundant halos exactly like shards on different GPUs, run on their own
+    streams from their own host threads and fill each other's gaps: +17 % on one MI355X
+    (tools/probe_streams.py).  Unlike shards on different GPUs, the group reproduces the
+    single-context run bit-for-bit INCLUDING D: the shards own whole 256-site blocks of the
+    canonical reduction tree (cut points and the internal halo width are multiples of 256)
+    and write their level-0 block partials into one shared buffer that is reduced once
+    (epv_run_mcmc_blocks / epv_reduce_blocks).  Drop-in for DeviceSampler inside
+    ShardedSampler, so it composes with the multi-GPU sharding."""
+
+    H_INT = 512        # internal halo columns: >= 6 * 60 + 2 and a multiple of 256
+    BLOCK = 256
+
+    def __init__(self, device=0, shards=2):
+        from concurrent.futures import ThreadPoolExecutor
+        from .sampler import DeviceSampler
+        self.device, self.k_req = device, max(1, int(shards))
+        self.subs = [DeviceSampler(device) for _ in range(self.k_req)]
+        self.pool = ThreadPoolExecutor(max_workers=self.k_req)
+        self.n_sites = self.n_nodes = self.B = 0
+        self.capacity_events = []
+        self._auto_grow = False
+        self._blocks, self._blocks_batch = None, 0
+        self.outer = (0, 0)
+        self.halo_mode = False
+
+    # ---- plumbing
+    @property
+    def auto_grow(self):
+        return self._auto_grow
+
+    @auto_grow.setter
+    def auto_grow(self, v):
+        self._auto_grow = bool(v)
+        for s in self.subs:
+            s.auto_grow = bool(v)
+
+    def close(self):
+        if self._blocks is not None:
+            self.subs[0].dev_free(self._blocks)
+            self._blocks = None
+        for s in self.subs:
+            s.close()
+        self.pool.shutdown(wait=True)
+
+    def _each(self, fn):
+        """run fn(j, sub) for every shard from its own host thread; results in shard order"""
+        if len(self.subs) == 1:
+            return [fn(0, self.subs[0])]
+        return [f.result() for f in [self.pool.submit(fn, j, s) for j, s in enumerate(self.subs)]]
+
+    def set_tree(self, tree):
+        self.n_nodes, self.B = tree.n_nodes, tree.n_nodes - 1
+        for s in self.subs:
+            s.set_tree(tree)
+
+    def set_model(self, model):
+        for s in self.subs:
+            s.set_model(model)
+
+    def upload_paths(self, fp, capacity=0, global_site_offset=0, n_global=None):
+        n, H, Q = fp.n_sites, self.H_INT, self.BLOCK
+        k = self.k_req
+        while k > 1 and n < k * (2 * H + 2 * Q):      # every shard must own more than its halos
+            k -= 1
+        for s in self.subs[k:]:
+            s.close()
+        self.subs = self.subs[:k]
+        cuts = [0] + [int(round(j * n / float(k) / Q)) * Q for j in range(1, k)] + [n]
+        self.a, self.b = cuts[:-1], cuts[1:]                       # pieces of [0, n)
+        self.lo = [a - (H if j > 0 else 0) for j, a in enumerate(self.a)]
+        self.hi = [b + (H if j < k - 1 else 0) for j, b in enumerate(self.b)]
+        if capacity == 0:
+            capacity = int(max(16, 2 * (fp.counts().max() if n else 0) + 8))
+        n_global = global_site_offset + n if n_global is None else n_global
+        for j, s in enumerate(self.subs):
+            s.upload_paths(fp.slice_sites(self.lo[j], self.hi[j]) if k > 1 else fp, capacity,
+                           global_site_offset + self.lo[j], n_global)
+        self.n_sites = n
+        self.halo_mode = False
+        self.outer = (0, 0)
+        self._drop_blocks()     # the halos are set by set_halo() (ShardedSampler) or by reset()
+
+    def _drop_blocks(self):
+        if self._blocks is not None:
+            self.subs[0].dev_free(self._blocks)
+        self._blocks, self._blocks_batch = None, 0
+
+    # ---- halos
+    def set_halo(self, left, right):
+        """outer halo blocks of the whole group (multi-GPU); the internal ones are managed here"""
+        if (left, right) != self.outer:
+            self._drop_blocks()          # ownership of the edge blocks changed
+        self.outer, self.halo_mode = (left, right), True
+        k, H = len(self.subs), self.H_INT
+        for j, s in enumerate(self.subs):
+            s.set_halo(left if j == 0 else H, right if j == k - 1 else H)
+
+    def halo_phases_left(self):
+        return min(s.halo_phases_left() for s in self.subs)
+
+    def _locate(self, first, count):
+        for j in range(len(self.subs)):
+            if self.a[j] <= first < self.b[j]:
+                if first + count > self.hi[j]:
+                    raise ValueError("column range straddles two shards of the group")
+                return j, first - self.lo[j]
+        raise ValueError("bad column range")
+
+    def column_bytes(self):
+        return self.subs[0].column_bytes()
+
+    def get_columns(self, first, count):
+        j, f = self._locate(first, count)
+        return self.subs[j].get_columns(f, count)
+
+    def put_columns(self, first, count, buf):
+        j, f = self._locate(first, count)
+        self.subs[j].put_columns(f, count, buf)
+
+    def _refresh_internal(self):
+        k, H = len(self.subs), self.H_INT
+        cap = max(s.capacity() for s in self.subs)
+        for s in self.subs:
+            if s.capacity() != cap:
+                s.set_capacity(cap)
+        for j in range(k - 1):
+            L, R = self.subs[j], self.subs[j + 1]
+            L.copy_columns_to(self.b[j] - H - self.lo[j], H, R, 0)          # L's edge -> R's left halo
+            R.copy_columns_to(H, H, L, self.b[j] - self.lo[j])              # R's edge -> L's right halo
+        if k > 1:
+            self.set_halo(*self.outer)                                      # marks them fresh
+
+    # ---- the SingleSiteSampler surface
+    def reset(self):
+        self._refresh_internal()
+        self._each(lambda j, s: s.reset())
+
+    def sweep(self, n_sweeps, seed, sweep_base=0):
+        if len(self.subs) > 1 and self.halo_phases_left() < 3 * n_sweeps:
+            done = 0
+            nacc = 0
+            while done < n_sweeps:
+                kk = min(n_sweeps - done, self.halo_phases_left() // 3)
+                if kk == 0:
+                    self.reset()
+                    continue
+                nacc += sum(self._each(lambda j, s: s.sweep(kk, seed, sweep_base + done)))
+                done += kk
+            return nacc
+        return sum(self._each(lambda j, s: s.sweep(n_sweeps, seed, sweep_base)))
+
+    def run_mcmc(self, burn_in, batch, seed, sweep_base=0, average=True):
+        if len(self.subs) == 1:
+            return self.subs[0].run_mcmc(burn_in, batch, seed, sweep_base, average)
+        if self.halo_phases_left() < 3 * (burn_in + batch):
+            raise RuntimeError("internal halo of %d columns is too narrow for %d sweeps without a "
+                               "reset()" % (self.H_INT, burn_in + batch))
+        nb_total = (self.n_sites + self.BLOCK - 1) // self.BLOCK
+        V = self.B * 16
+        if self._blocks is None or self._blocks_batch < batch:
+            self._drop_blocks()
+            self._blocks = self.subs[0].dev_alloc(batch * nb_total * V * 8)
+            self._blocks_batch = batch
+        nacc = sum(self._each(lambda j, s: s.run_mcmc_blocks(burn_in, batch, seed, sweep_base, self._blocks,
+                                                             nb_total, self.lo[j] // self.BLOCK)))
+        for s in self.subs:
+            self.capacity_events += s.capacity_events
+            s.capacity_events = []
+        J, D = self.subs[0].reduce_blocks(self._blocks, nb_total, batch, average)
+        return J, D, nacc
+
+    def scale_jump_times(self, new_branches):
+        for s in self.subs:
+            s.scale_jump_times(new_branches)
+
+    def _owned_slices(self):
+        k = len(self.subs)
+        return [(0 if j == 0 else self.a[j] - self.lo[j], self.b[j] - self.lo[j]) for j in range(k)]
+
+    def paths(self):
+        if len(self.subs) == 1:
+            return self.subs[0].paths()
+        ps = self._each(lambda j, s: s.paths())
+        return concat_sites([p.slice_sites(lo, hi) for p, (lo, hi) in zip(ps, self._owned_slices())])
+
+    def tri_llh(self):
+        ts = [s.tri_llh() for s in self.subs]
+        return np.concatenate([t[lo:hi] for t, (lo, hi) in zip(ts, self._owned_slices())])
+
+    def capacity(self):
+        return max(s.capacity() for s in self.subs)
+
+    def set_capacity(self, capacity):
+        for s in self.subs:
+            s.set_capacity(capacity)
+
+    def counters(self):
+        out = {}
+        for s in self.subs:
+            for key, v in s.counters().items():
+                out[key] = out.get(key, 0) + v
+        out["sweeps"] = self.subs[0].counters()["sweeps"]
+        return out
+
+    def set_timing(self, on):
+        for s in self.subs:
+            s.set_timing(on)
+
+    def kernel_time_ms(self):
+        """launch-weighted mean duration of the shards' colour-phase launches, and their number"""
+        tot, n = 0.0, 0
+        for s in self.subs:
+            ms, nl = s.kernel_time_ms()
+            tot += ms * nl
+            n += nl
+        return (tot / n if n else 0.0), n

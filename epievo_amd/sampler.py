@@ -40,7 +40,8 @@ ABI_SYMBOLS = [
     "epv_halo_phases_left", "epv_reset", "epv_sweep",
     "epv_sweep_phase", "epv_run_mcmc", "epv_run_mcmc_sums", "epv_get_sufficient_statistics", "epv_scale_jump_times",
     "epv_paths_total_jumps", "epv_download_paths", "epv_get_tri_llh", "epv_column_bytes",
-    "epv_get_columns", "epv_put_columns", "epv_get_counters", "epv_kernel_time_ms",
+    "epv_get_columns", "epv_put_columns", "epv_copy_columns", "epv_dev_alloc", "epv_dev_free",
+    "epv_run_mcmc_blocks", "epv_reduce_blocks", "epv_get_counters", "epv_kernel_time_ms",
     "epv_set_timing",
 ]
 
@@ -90,6 +91,12 @@ def lib():
         L.epv_column_bytes.restype = C.c_uint64
         L.epv_get_columns.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
         L.epv_put_columns.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
+        L.epv_copy_columns.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64]
+        L.epv_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+        L.epv_dev_free.argtypes = [vp, vp]
+        L.epv_run_mcmc_blocks.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp, C.c_uint64,
+                                          C.c_uint64, u64p]
+        L.epv_reduce_blocks.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, dp, dp]
         L.epv_get_counters.argtypes = [vp, C.POINTER(_Counters)]
         L.epv_kernel_time_ms.argtypes = [vp, dp, u64p]
         L.epv_set_timing.argtypes = [vp, C.c_int]
@@ -255,6 +262,30 @@ class DeviceSampler:
     def put_columns(self, first, count, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         self._ck(self.L.epv_put_columns(self.h, first, count, buf.ctypes.data_as(C.c_void_p)))
+
+    # ---- several shards on one GPU (see epievo_amd.parallel.LocalGroup)
+    def copy_columns_to(self, first, count, other, other_first):
+        self._ck(self.L.epv_copy_columns(self.h, first, count, other.h, other_first))
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p(0)
+        self._ck(self.L.epv_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        self._ck(self.L.epv_dev_free(self.h, p))
+
+    def run_mcmc_blocks(self, burn_in, batch, seed, sweep_base, d_blocks, n_blocks_total, block_offset):
+        nacc = C.c_uint64(0)
+        self._ck_mcmc(self.L.epv_run_mcmc_blocks(self.h, burn_in, batch, seed, sweep_base, d_blocks,
+                                                 n_blocks_total, block_offset, C.byref(nacc)))
+        return int(nacc.value)
+
+    def reduce_blocks(self, d_blocks, n_blocks_total, batch, average=True):
+        J, D = np.zeros(self.B * 8), np.zeros(self.B * 8)
+        self._ck(self.L.epv_reduce_blocks(self.h, d_blocks, n_blocks_total, batch, int(average),
+                                          _p(J, C.c_double), _p(D, C.c_double)))
+        return J, D
 
     def counters(self):
         c = _Counters()

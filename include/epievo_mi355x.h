@@ -184,6 +184,26 @@ int epv_get_tri_llh(epv_ctx *ctx, double *out);
 uint64_t epv_column_bytes(const epv_ctx *ctx);
 int epv_get_columns(epv_ctx *ctx, uint64_t first, uint64_t count, void *packed);
 int epv_put_columns(epv_ctx *ctx, uint64_t first, uint64_t count, const void *packed);
+/* the same between two contexts of ONE GPU (equal tree and capacity), without leaving the device */
+int epv_copy_columns(epv_ctx *src, uint64_t src_first, uint64_t count, epv_ctx *dst, uint64_t dst_first);
+
+/* ---- several shards on one GPU (new; the reference is single-process).  Two or three
+ * contexts on one device, each owning a contiguous range of 256-aligned site blocks plus
+ * redundant halos, run their colour phases on their own streams so that the ramps and tails
+ * of the dependent kernels overlap (+17 % on one MI355X).  To keep J AND D bit-identical to the
+ * unsharded run the statistics are not reduced per shard: every shard writes the level-0
+ * partials of its OWNED 256-site blocks, per batch sweep, into one buffer shared by the group
+ * (epv_run_mcmc_blocks; d_blocks[w][block][16 (N-1)] doubles, block_offset = index of the
+ * shard's local block 0 in the group), and one canonical reduction (epv_reduce_blocks, on any
+ * context of the group) adds them up exactly as run_mcmc does on one context.
+ * epv_dev_alloc returns zero-filled device memory (blocks nobody owns must read as 0). */
+int epv_dev_alloc(epv_ctx *ctx, uint64_t bytes, void **device_ptr);
+int epv_dev_free(epv_ctx *ctx, void *device_ptr);
+int epv_run_mcmc_blocks(epv_ctx *ctx, uint64_t burn_in, uint64_t batch, uint64_t seed, uint32_t sweep_base,
+                        double *d_blocks, uint64_t n_blocks_total, uint64_t block_offset,
+                        uint64_t *n_accepted);
+int epv_reduce_blocks(epv_ctx *ctx, const double *d_blocks, uint64_t n_blocks_total, uint64_t batch,
+                      int average, double *J, double *D);
 
 int epv_get_counters(epv_ctx *ctx, epv_counters *out);
 

@@ -25,8 +25,16 @@ def _tmp(name, text):
     d = os.path.join(tempfile.gettempdir(), "epv_tests_%d" % os.getuid())
     os.makedirs(d, exist_ok=True)
     p = os.path.join(d, name)
-    with open(p, "w") as f:
+    # several rank processes of one test write the same file: never expose a truncated one
+    try:
+        if open(p).read() == text:
+            return p
+    except OSError:
+        pass
+    tmp = "%s.%d.tmp" % (p, os.getpid())
+    with open(tmp, "w") as f:
         f.write(text)
+    os.replace(tmp, p)
     return p
 
 

@@ -1,6 +1,6 @@
 """Worker for the world_size>1 tests: runs ShardedSampler on a slice of a genome and
 writes its owned paths + J/D so the parent test can compare with the unsharded run.
-  python dist_worker.py <backend: oracle|hip> <cfg> <n_own> <burn> <batch> <em_iters> <outdir>
+  python dist_worker.py <backend: oracle|hip|hipgroup> <cfg> <n_own> <burn> <batch> <em_iters> <outdir>
 Rendezvous via env (RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT); comm backend is gloo."""
 import os
 import sys
@@ -25,6 +25,9 @@ def main():
     if backend == "oracle":
         from fake_device import OracleDevice
         ss = ShardedSampler(comm, device_factory=OracleDevice)
+    elif backend == "hipgroup":      # two concurrent contexts per rank (LocalGroup) under the rank sharding
+        from epievo_amd.parallel import LocalGroup
+        ss = ShardedSampler(comm, device=0, device_factory=lambda dev: LocalGroup(dev, 2))
     else:
         ss = ShardedSampler(comm, device=0)
     ss.setup(model, tree, own, fp.n_sites, capacity=16, sweeps_per_refresh=burn + batch)

@@ -117,3 +117,6 @@ def test_sharded_hip_two_ranks_one_gpu():
     ranks = _run_ranks(2, "hip", "tree", n_own, burn, batch, iters, 29655)
     ref_res, ref_paths, tree = _unsharded(_HipEngine, "tree", 2 * n_own, burn, batch, iters)
     _check(ranks, ref_res, ref_paths, tree.n_nodes, n_own)
+    # the same with two concurrent contexts per rank (LocalGroup inside each rank's shard)
+    ranks = _run_ranks(2, "hipgroup", "tree", n_own, burn, batch, iters, 29657)
+    _check(ranks, ref_res, ref_paths, tree.n_nodes, n_own)
