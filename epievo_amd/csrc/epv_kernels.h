@@ -368,8 +368,11 @@ __device__ __forceinline__ double gtp(double r0, double r1, double h, double den
 //   On a large tree the pool alone (64 lanes x (N-1) branches x ~2 records x 16 B = 84 KB for
 //   the 16-leaf tree) would leave ONE wave per CU; with the slab in HBM/L2 only the node table
 //   stays in LDS and the kernel keeps its 3 waves/SIMD.
+#ifndef EPV_PROPOSE_WAVES
+#define EPV_PROPOSE_WAVES 3   /* waves per SIMD the register allocation aims for (<= 168 VGPRs) */
+#endif
 template <bool GPOOL>
-__global__ __launch_bounds__(64, 3) void epv_mh_propose_kernel(
+__global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
     uint64_t first, uint64_t last, uint32_t pool_entries, unsigned long long *counters,
     double *gpool) {
