@@ -10,7 +10,12 @@
 //    reset(model) re-derives the cached log-likelihoods after a model change, and
 //    download(paths) brings them back when the driver wants to write them;
 //  * the reference threads one std::mt19937 through every call; the parallel schedule
-//    uses a counter-based stream, so run_mcmc takes (seed, em_iteration) instead.
+//    uses a counter-based stream, so run_mcmc takes (seed, em_iteration) instead;
+//  * the EM driver's path (reset / run_mcmc / scale_jump_times / download) runs TWO contexts
+//    per GPU when the genome is long enough (EPV_CONTEXTS_PER_GPU, default 2): each owns a
+//    range of whole 256-site blocks plus 512 redundant halo columns, their dependent kernels
+//    overlap on two streams, and the statistics come from shared block partials, so every
+//    result is bit-identical to one context.
 #ifndef EPV_SAMPLER_HPP
 #define EPV_SAMPLER_HPP
 
@@ -77,7 +82,17 @@ public:
 private:
   void check(int rc, const char *what);
   void check_mcmc(int rc, const char *what);
+  void check_on(epv_ctx *c, int rc, const char *what);
+  bool grouped() const { return group_.size() > 1; }
+  void drop_group();          // back to the single context ctx_
+  void refresh_group();       // equal capacities, internal halo columns, fresh halo marks
   epv_ctx *ctx_;
+  int device_;
+  int contexts_wanted_ = 2;
+  std::vector<epv_ctx *> group_;            // group_[0] == ctx_ when several contexts share the GPU
+  std::vector<uint64_t> lo_, a_, b_, hi_;   // local range [lo, hi) and owned range [a, b) of each
+  void *d_blocks_ = nullptr;                // [batch][blocks][16 (N-1)] level-0 partials of the group
+  uint64_t blocks_batch_ = 0;
   uint32_t capacity_;
   int n_nodes_ = 0;
   uint64_t n_sites_ = 0;

@@ -42,7 +42,7 @@ def _newick(tree):
 @pytest.mark.parametrize("cfg,optimize", [("tree", False), ("tree", True), ("bal16", True)])
 def test_est_params_histories_matches_oracle_em(tmp_path, cfg, optimize):
     """BASELINE configs 3 and 5 in miniature (tree.nwk; a balanced 16-leaf tree with -b)"""
-    model, tree, fp = simulate(cfg, 3000 if cfg == "tree" else 800, seed=21)
+    model, tree, fp = simulate(cfg, 4000 if cfg == "tree" else 800, seed=21)
     d = str(tmp_path)
     open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
     open(d + "/t.nwk", "w").write(TREE_NWK_TEXT if cfg == "tree" else _newick(tree))
