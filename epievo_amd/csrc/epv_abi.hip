@@ -43,6 +43,8 @@ struct epv_ctx {
   uint64_t partial_cap = 0;
   double *d_jd_acc = nullptr;  // [B*16] accumulated over batch sweeps
   double *d_scale = nullptr;
+  double *d_lvl = nullptr;      // level outputs of epv_reduce_blocks (all batch sweeps at once)
+  uint64_t lvl_cap = 0;
   uint8_t *d_stage = nullptr;   // packed-column staging for the halo exchange (grown on demand)
   uint64_t stage_cap = 0;
   EpvIndepConst *d_indep = nullptr;  // [N] constants of the site-independent model
@@ -328,7 +330,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage);
+  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->stream);
@@ -896,25 +898,31 @@ EPV_API int epv_reduce_blocks(epv_ctx *c, const double *d_blocks, uint64_t nb_to
   int rc = ensure_partials(c, nb_total);
   if (rc) return rc;
   const uint32_t V = c->S.B * 16u;
-  HIP_TRY(c, hipMemsetAsync(c->d_jd_acc, 0, V * sizeof(double), c->stream));
-  for (uint64_t w = 0; w < batch; ++w) {
-    const double *in = d_blocks + w * nb_total * V;
-    uint64_t m = nb_total;
-    int cur = 1;   // level outputs alternate d_partial[1], d_partial[0], ... as in launch_suffstats
-    if (m == 1) {
-      hipLaunchKernelGGL(epv_accumulate_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream, c->d_jd_acc, in, V);
-      continue;
-    }
-    while (m > 1) {
-      const uint64_t mb = (m + 255u) / 256u;
-      hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb, V / 16u), dim3(256), 0, c->stream, in, m, V,
-                         c->d_partial[cur]);
-      in = c->d_partial[cur];
-      m = mb;
-      cur ^= 1;
-    }
-    hipLaunchKernelGGL(epv_accumulate_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream, c->d_jd_acc, in, V);
+  // all `batch` reductions level by level (grid z = sweep), then one sequential accumulation
+  const uint64_t mb1 = (nb_total + 255u) / 256u, mb2 = (mb1 + 255u) / 256u;
+  const uint64_t need = batch * (mb1 + mb2) * V;
+  if (need > c->lvl_cap) {
+    dfree(c->d_lvl);
+    c->lvl_cap = 0;
+    HIP_TRY(c, hipMalloc(&c->d_lvl, need * sizeof(double)));
+    c->lvl_cap = need;
   }
+  const double *in = d_blocks;
+  uint64_t m = nb_total, in_stride = nb_total * V;
+  double *outs[2] = {c->d_lvl, c->d_lvl + batch * mb1 * V};
+  int cur = 0;
+  while (m > 1) {
+    const uint64_t mb = (m + 255u) / 256u;
+    if (cur > 1) return fail(c, EPV_ERR_ARG, "more than 2^24 blocks per group");
+    hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb, V / 16u, (unsigned)batch), dim3(256), 0, c->stream,
+                       in, m, V, outs[cur], in_stride, mb * V);
+    in = outs[cur];
+    in_stride = mb * V;
+    m = mb;
+    ++cur;
+  }
+  hipLaunchKernelGGL(epv_accumulate_seq_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream, c->d_jd_acc, in, V,
+                     batch, in_stride);
   HIP_TRY(c, hipGetLastError());
   std::vector<double> jd(V);
   HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_jd_acc, V * sizeof(double), hipMemcpyDeviceToHost, c->stream));

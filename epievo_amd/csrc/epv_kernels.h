@@ -1247,8 +1247,11 @@ __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t fi
 // sums 256 consecutive (aligned) entries of one group of 16 value columns (blockIdx.y) in
 // balanced order
 __global__ __launch_bounds__(256) void epv_tree_reduce_kernel(const double *in, uint64_t m,
-                                                              uint32_t V, double *out) {
+                                                              uint32_t V, double *out,
+                                                              uint64_t in_stride = 0, uint64_t out_stride = 0) {
   __shared__ double s_part[4][16];
+  in += (uint64_t)blockIdx.z * in_stride;     // blockIdx.z: one of several independent reductions
+  out += (uint64_t)blockIdx.z * out_stride;   // (the batch sweeps of epv_reduce_blocks)
   const int lane = epv_lane();
   const uint32_t wave = threadIdx.x >> 6;
   const uint64_t idx_in = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -1263,6 +1266,17 @@ __global__ __launch_bounds__(256) void epv_tree_reduce_kernel(const double *in, 
   if (threadIdx.x < 16)
     out[(uint64_t)blockIdx.x * V + g * 16u + threadIdx.x] =
         (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+}
+
+// acc[i] = ((0 + t_0[i]) + t_1[i]) + ... : the same sequence of additions as `batch` calls of
+// the kernel below on a zeroed accumulator
+__global__ void epv_accumulate_seq_kernel(double *acc, const double *tot, uint32_t count, uint64_t batch,
+                                          uint64_t stride) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double a = 0.0;
+  for (uint64_t w = 0; w < batch; ++w) a += tot[w * stride + i];
+  acc[i] = a;
 }
 
 // acc[i] += one[i]  (J_all_sites += J_one_site, SingleSiteSampler.cpp:582-586)
