@@ -46,3 +46,24 @@ def test_group_equals_single_context(cfg, n, k):
     assert g.sweep(100, 3, sweep_base=40) == d.sweep(100, 3, sweep_base=40)
     assert orc.paths_equal(g.paths(), d.paths())
     g.close()
+
+
+def test_group_capacity_overflow_follows_single_context():
+    """a deliberately tiny capacity: both absorb the overflow (auto_grow) and stay identical"""
+    model, tree, fp = simulate("pair", 6000, seed=8)
+    cap = int(fp.counts().max())
+    d = _single(tree, model, fp, cap)
+    d.auto_grow = True
+    g = LocalGroup(0, 2)
+    g.set_tree(tree); g.set_model(model); g.upload_paths(fp, cap)
+    g.auto_grow = True
+    assert len(g.subs) == 2
+    for it in range(3):
+        d.reset(); g.reset()
+        Jd, Dd, nd = d.run_mcmc(1, 2, 4, sweep_base=3 * it)
+        Jg, Dg, ng = g.run_mcmc(1, 2, 4, sweep_base=3 * it)
+        assert nd == ng and np.array_equal(Jd, Jg) and np.array_equal(Dd, Dg)
+        assert orc.paths_equal(g.paths(), d.paths())
+    g.reset()
+    assert d.capacity() == g.capacity() > cap and d.capacity_events and g.capacity_events
+    g.close()
