@@ -426,7 +426,7 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   HIP_TRY(c, hipMalloc(&c->S.prop_states, B * c->S.phase_cap * c->S.W * sizeof(uint64_t)));
   // one task region per counter shard, sized for the worst case of the blocks that use it
   c->S.task_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u * B;
-  HIP_TRY(c, hipMalloc(&c->S.tasks, c->S.task_cap * EPV_SHARDS * sizeof(unsigned long long)));
+  HIP_TRY(c, hipMalloc(&c->S.tasks, c->S.task_cap * EPV_SHARDS * 2u * sizeof(unsigned long long)));
   HIP_TRY(c, hipMemsetAsync(c->S.meta, 0, 2u * E, c->stream));
   // staging of the CSR form
   DevTmp<uint8_t> d_init;

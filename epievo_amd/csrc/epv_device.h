@@ -43,7 +43,8 @@ struct EpvDev {
   uint8_t *prop_flag; // [phase_cap] 1 = the pending proposal overflowed the capacity
   uint64_t *prop_states;  // [B][phase_cap][W] sampled segment end states of the pending proposal, 1 bit each
   unsigned long long *tasks;  // dirty (branch<<40 | site) pairs of the current colour phase,
-                              // EPV_SHARDS regions of task_cap entries each
+                              // EPV_SHARDS x 2 regions of task_cap entries each (four buckets by
+                              // segment count: each region is filled from both ends)
   uint64_t task_cap;
   uint64_t phase_cap;  // max sites of one colour phase; the hand-over arrays are indexed by
                        // the phase-local thread id (site = s0 + 3*tid) so they are written densely
@@ -63,7 +64,7 @@ struct EpvIndepConst {
 };
 
 // counters[] slots
-enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_N = 4 };
+enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_TASKS2 = 4, EPV_CNT_N = 5 };
 // Every counter is sharded 64 ways with a 128-byte stride (one device-scope atomic word
 // saturates near 90 ops/us; 5000 waves hitting ONE word would serialise for ~60 us).
 // A block uses shard (blockIdx.x & 63); the host sums the shards.

@@ -492,7 +492,8 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
     //         rejection with dense lanes instead of making 64 lanes wait for 3.
     double log_prob = 0.0, orig_proposal = 0.0;
     unsigned long long dirty = 0ull;   // bit (node-1) & 63, flushed every 64 branches
-    unsigned long long multi = 0ull;   // ... of those, the branches with more than one segment
+    unsigned long long multi = 0ull;   // ... of those, the branches with an even bucket bit (K = 2 or K >= 4)
+    unsigned long long deep = 0ull;    // ... and those with K >= 3 (second region)
     {
       const uint32_t root_state = run ? (uint32_t)(S.meta[meta_idx(S, selM, 0u, site)] >> 7) : 0u;
       for (uint32_t node = 1u; node < S.N; ++node) {
@@ -570,40 +571,48 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
           orig_proposal += lp;
           if (!clean) {
             dirty |= 1ull << (b & 63u);
-            if (K > 1u) multi |= 1ull << (b & 63u);
+            // four buckets by segment count: K = 1 | 2 | 3 | >= 4
+            if (K == 2u || K >= 4u) multi |= 1ull << (b & 63u);
+            if (K >= 3u) deep |= 1ull << (b & 63u);
           }
         }
-        // flush the dirty (site, branch) pairs of the last <= 64 branches: ONE atomic per
-        // wave reserves the slots, the lanes fill them in.  A shard's region is filled from
-        // BOTH ends -- single-segment branches from the front, multi-segment ones from the
-        // back (counts packed lo/hi in one word) -- so that the waves of the jumps kernel,
-        // which take consecutive tasks, hold lanes with similar loop counts.
+        // flush the dirty (site, branch) pairs of the last <= 64 branches.  They are bucketed by
+        // segment count so that the waves of the jumps kernel, which take consecutive tasks,
+        // hold lanes with similar loop counts: a shard has two regions, each filled from BOTH
+        // ends (counts packed lo/hi in one word) -- region 0: K = 1 from the front, K = 2 from
+        // the back; region 1: K = 3 from the front, K >= 4 from the back.  One atomic per wave
+        // and region reserves the slots, the lanes fill them in.
         if ((b & 63u) == 63u || node + 1u == S.N) {
-          const uint32_t mineB = (uint32_t)__popcll(dirty & multi);
-          const uint32_t mineA = (uint32_t)__popcll(dirty) - mineB;
-          const uint32_t inclA = wave_incl_scan_u32(mineA), inclB = wave_incl_scan_u32(mineB);
-          const uint32_t totalA = __shfl(inclA, 63), totalB = __shfl(inclB, 63);
-          if (totalA | totalB) {
-            unsigned long long base = 0ull;
-            const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
-            if (lane == 0)
-              base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)],
-                               (unsigned long long)totalA | ((unsigned long long)totalB << 32));
-            const uint32_t baseA = __shfl((uint32_t)base, 0), baseB = __shfl((uint32_t)(base >> 32), 0);
-            unsigned long long *region = S.tasks + (unsigned long long)shard * S.task_cap;
-            unsigned long long slotA = (unsigned long long)baseA + (inclA - mineA);
-            unsigned long long slotB = S.task_cap - 1ull - ((unsigned long long)baseB + (inclB - mineB));
-            unsigned long long d = dirty;
-            while (d) {
-              const uint32_t bit = (uint32_t)(__ffsll((long long)d) - 1);
-              d &= d - 1ull;
-              const unsigned long long t = ((unsigned long long)((b & ~63u) + bit) << 40) | site;
-              if ((multi >> bit) & 1ull) region[slotB--] = t;
-              else region[slotA++] = t;
+          const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+#pragma unroll
+          for (uint32_t reg = 0; reg < 2u; ++reg) {
+            const unsigned long long mine_reg = reg ? (dirty & deep) : (dirty & ~deep);
+            const uint32_t mineB = (uint32_t)__popcll(mine_reg & multi);
+            const uint32_t mineA = (uint32_t)__popcll(mine_reg) - mineB;
+            const uint32_t inclA = wave_incl_scan_u32(mineA), inclB = wave_incl_scan_u32(mineB);
+            const uint32_t totalA = __shfl(inclA, 63), totalB = __shfl(inclB, 63);
+            if (totalA | totalB) {
+              unsigned long long base = 0ull;
+              if (lane == 0)
+                base = atomicAdd(&counters[EPV_CNT_IDX(reg ? EPV_CNT_TASKS2 : EPV_CNT_TASKS, shard)],
+                                 (unsigned long long)totalA | ((unsigned long long)totalB << 32));
+              const uint32_t baseA = __shfl((uint32_t)base, 0), baseB = __shfl((uint32_t)(base >> 32), 0);
+              unsigned long long *region = S.tasks + ((unsigned long long)shard * 2u + reg) * S.task_cap;
+              unsigned long long slotA = (unsigned long long)baseA + (inclA - mineA);
+              unsigned long long slotB = S.task_cap - 1ull - ((unsigned long long)baseB + (inclB - mineB));
+              unsigned long long d = mine_reg;
+              while (d) {
+                const uint32_t bit = (uint32_t)(__ffsll((long long)d) - 1);
+                d &= d - 1ull;
+                const unsigned long long t = ((unsigned long long)((b & ~63u) + bit) << 40) | site;
+                if ((multi >> bit) & 1ull) region[slotB--] = t;
+                else region[slotA++] = t;
+              }
             }
           }
           dirty = 0ull;
           multi = 0ull;
+          deep = 0ull;
         }
       }
     }
@@ -657,10 +666,12 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
            *c_nk = c_nk_[wave], *c_res = c_res_[wave], *c_tw = c_tw_[wave];
   const bool indep = indep_r0 > 0.0;   // epv_indep_update_paths: rates are not context dependent
   const uint32_t shard = blockIdx.y;   // one task-list region per counter shard
-  // the region is filled from both ends (front: single-segment branches, back: the others)
+  // two regions per shard, each filled from both ends: buckets K = 1, 2, 3, >= 4 in this order
   const unsigned long long packed = counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)];
-  const unsigned long long n_front = packed & 0xffffffffull, n_tasks = n_front + (packed >> 32);
-  const unsigned long long *tasks = S.tasks + (unsigned long long)shard * S.task_cap;
+  const unsigned long long packed2 = counters[EPV_CNT_IDX(EPV_CNT_TASKS2, shard)];
+  const unsigned long long n0 = packed & 0xffffffffull, n1 = n0 + (packed >> 32);
+  const unsigned long long n2 = n1 + (packed2 & 0xffffffffull), n_tasks = n2 + (packed2 >> 32);
+  const unsigned long long *tasks = S.tasks + (unsigned long long)shard * 2u * S.task_cap;
   const uint64_t n = S.n;
   const uint32_t B = S.B, C = S.C;
   // Only the first `tasks_per_wave` lanes of a wave own a task; the others are pure
@@ -685,7 +696,10 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
     unsigned long long word = 0ull;
     bool ovf = false;
     if (active) {
-      const unsigned long long task = ti < n_front ? tasks[ti] : tasks[S.task_cap - 1ull - (ti - n_front)];
+      const unsigned long long task = ti < n0   ? tasks[ti]
+                                      : ti < n1 ? tasks[S.task_cap - 1ull - (ti - n0)]
+                                      : ti < n2 ? tasks[S.task_cap + (ti - n1)]
+                                                : tasks[2ull * S.task_cap - 1ull - (ti - n2)];
       site = task & 0xffffffffffull;
       b = (uint32_t)(task >> 40);
       node = b + 1u;
@@ -902,8 +916,11 @@ __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
   // into the running total and clear them for the next propose kernel
   if (blockIdx.x == 0 && threadIdx.x < EPV_SHARDS) {
     const unsigned long long packed = counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)];
-    counters[EPV_CNT_IDX(EPV_CNT_COOP, threadIdx.x)] += (packed & 0xffffffffull) + (packed >> 32);
+    const unsigned long long packed2 = counters[EPV_CNT_IDX(EPV_CNT_TASKS2, threadIdx.x)];
+    counters[EPV_CNT_IDX(EPV_CNT_COOP, threadIdx.x)] +=
+        (packed & 0xffffffffull) + (packed >> 32) + (packed2 & 0xffffffffull) + (packed2 >> 32);
     counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)] = 0ull;
+    counters[EPV_CNT_IDX(EPV_CNT_TASKS2, threadIdx.x)] = 0ull;
   }
 }
 
@@ -945,7 +962,7 @@ __global__ __launch_bounds__(256) void epv_init_tasks_kernel(EpvDev S, uint32_t 
       base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)], (unsigned long long)total);
     base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0) << 32) |
            (unsigned long long)__shfl((uint32_t)base, 0);
-    if (valid) S.tasks[(unsigned long long)shard * S.task_cap + base + (incl - mine)] = site;
+    if (valid) S.tasks[(unsigned long long)shard * 2u * S.task_cap + base + (incl - mine)] = site;
   }
 }
 
@@ -1154,7 +1171,7 @@ __global__ __launch_bounds__(64) void epv_indep_propose_kernel(EpvDev S, const E
           base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)], (unsigned long long)total);
         base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0) << 32) |
                (unsigned long long)__shfl((uint32_t)base, 0);
-        unsigned long long slot = (unsigned long long)shard * S.task_cap + base + (incl_t - mine);
+        unsigned long long slot = (unsigned long long)shard * 2u * S.task_cap + base + (incl_t - mine);
         unsigned long long d = dirty;
         while (d) {
           const uint32_t bit = (uint32_t)(__ffsll((long long)d) - 1);
