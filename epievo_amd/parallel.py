@@ -255,12 +255,23 @@ class LocalGroup:
             s.auto_grow = bool(v)
 
     def close(self):
-        if self._blocks is not None:
-            self.subs[0].dev_free(self._blocks)
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
+        try:
+            if self._blocks is not None and self.subs and self.subs[0].h:
+                self.subs[0].dev_free(self._blocks)
+        finally:
             self._blocks = None
-        for s in self.subs:
-            s.close()
-        self.pool.shutdown(wait=True)
+            for s in self.subs:
+                s.close()
+            self.pool.shutdown(wait=True)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _each(self, fn):
         """run fn(j, sub) for every shard from its own host thread; results in shard order"""
