@@ -142,6 +142,13 @@ def main():
                      "--gpus %d ..." % (args.gpus, args.gpus))
         args.gpus = world
 
+    # stdout carries exactly one JSON line (rank 0).  Libraries print there too (RCCL's version
+    # banner, gloo's connection notes): send everything else written to fd 1 to stderr and
+    # restore the descriptor only for the result line.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from epievo_amd import host
     from epievo_amd.parallel import ShardedSampler, TorchComm, NullComm, LocalGroup
@@ -252,7 +259,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(model, tree, fp_own)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
