@@ -15,8 +15,8 @@ O(8) host M-step are outside it.
 For N > 1 it is launched by torch.distributed.run (one rank per GPU, RCCL): the genome
 of N * n sites is cut into contiguous shards with wide halos that each rank updates
 redundantly (the RNG is keyed by the global site index), so one step needs exactly two
-exchanges: a halo refresh before reset() and one all-gather of J/D afterwards
-(epievo_amd/parallel.py).
+exchanges: a halo refresh before reset() and one all-gather of the J/D rows afterwards,
+both on device buffers handed to RCCL as they are (epievo_amd/parallel.py).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -151,9 +151,8 @@ def main():
 
     import torch
     from epievo_amd import host
-    from epievo_amd.parallel import ShardedSampler, TorchComm, NullComm, LocalGroup
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from common import ref_test_model, config
+    from epievo_amd.parallel import ShardedSampler, TorchComm, NullComm, LocalGroup, shard_cuts
+    from epievo_amd.workloads import ref_test_model, config
 
     dist = None
     # EPV_BENCH_FORCE_DIST=1 under torchrun with one rank exercises the RCCL set-up and the
@@ -176,15 +175,20 @@ def main():
     tree = config(args.config)
     n_local = args.sites
     n_global = n_local * world
+    # contiguous shards cut on whole rows of the statistics tree (16384 sites): n_local sites per
+    # GPU on average, at most one row more or less on any one
+    cuts = shard_cuts(n_global, world)
+    n_own = cuts[rank + 1] - cuts[rank]
     # every rank simulates its own shard (+ halos come from the neighbours' edges)
-    fp_own = host.simulate(model, tree, n_local, SEED + rank)
-    kbar = len(fp_own.jumps) / float(n_local * (tree.n_nodes - 1))
+    fp_own = host.simulate(model, tree, n_own, SEED + rank)
+    kbar = len(fp_own.jumps) / float(n_own * (tree.n_nodes - 1))
 
     k_local = max(1, args.shards_per_gpu)
     ss = ShardedSampler(comm, device=local_rank,
-                        device_factory=(lambda dev: LocalGroup(dev, k_local)) if k_local > 1 else None)
+                        device_factory=(lambda dev: LocalGroup(dev, k_local, BURN_IN + BATCH)) if k_local > 1 else None)
     # 16 jump slots per (site, branch) on the short trees; the T = 1 branch picks its own
-    ss.setup(model, tree, fp_own, n_global, capacity=16 if args.config != "pair" else 0)
+    ss.setup(model, tree, fp_own, cuts, capacity=16 if args.config != "pair" else 0,
+             sweeps_per_refresh=BURN_IN + BATCH)
     ss.dev.set_timing(False)
 
     def barrier():

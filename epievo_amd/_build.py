@@ -2,6 +2,8 @@
 
   build_hip()    hipcc --offload-arch=gfx950  -> epievo_amd/libepievo_mi355x.so
                  (the C-ABI of include/epievo_mi355x.h: HIP kernels + host glue)
+  build_comm()   hipcc (host code) + librccl  -> epievo_amd/libepv_rccl.so
+                 (the C-ABI of include/epievo_mi355x_comm.h: halo exchange + statistics all-gather)
   build_host()   g++                          -> epievo_amd/libepv_host.so
                  (model / M-step / file formats / synthetic-input simulator)
   build_cli()    g++                          -> epievo_amd/bin/epievo_*  (drop-in CLIs)
@@ -19,6 +21,7 @@ HOST = os.path.join(CSRC, "host")
 INCLUDE = os.path.join(ROOT, "include")
 
 HIP_SO = os.path.join(PKG, "libepievo_mi355x.so")
+COMM_SO = os.path.join(PKG, "libepv_rccl.so")
 HOST_SO = os.path.join(PKG, "libepv_host.so")
 BIN_DIR = os.path.join(PKG, "bin")
 
@@ -63,6 +66,19 @@ def build_hip(force=False):
     return HIP_SO
 
 
+def build_comm(force=False):
+    """the exchange layer (include/epievo_mi355x_comm.h): host code on the HIP runtime, RCCL
+    linked directly.  Its own library so that the kernels' library has no RCCL dependency."""
+    src = os.path.join(CSRC, "comm", "epv_comm.cpp")
+    deps = [src, os.path.join(INCLUDE, "epievo_mi355x_comm.h"), os.path.join(INCLUDE, "epievo_mi355x.h")]
+    if not force and _newer(COMM_SO, deps):
+        return COMM_SO
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc_path()))), "lib")
+    _run([hipcc_path(), "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+          "-I", INCLUDE, "-o", COMM_SO, src, "-L", rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib])
+    return COMM_SO
+
+
 def build_host(force=False):
     srcs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith((".cpp", ".hpp"))]
     if not force and _newer(HOST_SO, srcs):
@@ -84,6 +100,7 @@ def build_oracle(with_ref=True):
 def build_all(force=False):
     build_host(force)
     build_hip(force)
+    build_comm(force)
     cli = os.path.join(HOST, "cli")
     if os.path.isdir(cli):
         build_cli(force)
@@ -101,9 +118,9 @@ def build_cli(force=False):
             continue
         out = os.path.join(BIN_DIR, f[:-4])
         srcs = [os.path.join(cli, f)] + common
-        if force or not _newer(out, srcs + [HIP_SO]):
+        if force or not _newer(out, srcs + [HIP_SO, COMM_SO, os.path.join(HOST, "epv_sampler.hpp")]):
             _run(["g++"] + [x for x in HOST_FLAGS if x not in ("-fPIC", "-fvisibility=hidden")] +
                  ["-I", HOST, "-I", INCLUDE, "-o", out] + srcs +
-                 ["-L", PKG, "-lepievo_mi355x", "-Wl,-rpath,$ORIGIN/.."])
+                 ["-pthread", "-L", PKG, "-lepievo_mi355x", "-lepv_rccl", "-Wl,-rpath,$ORIGIN/.."])
         outs.append(out)
     return outs

@@ -40,11 +40,13 @@ struct epv_ctx {
   unsigned long long *d_counters = nullptr;
   unsigned long long *h_counters = nullptr;  // pinned staging for the sharded counters
   double *d_partial[2] = {nullptr, nullptr};  // tree-reduction ping-pong
-  uint64_t partial_cap = 0;
+  uint64_t partial_cap[2] = {0, 0};   // doubles allocated in d_partial[0], [1]
   double *d_jd_acc = nullptr;  // [B*16] accumulated over batch sweeps
   double *d_scale = nullptr;
   double *d_lvl = nullptr;      // level outputs of epv_reduce_blocks (all batch sweeps at once)
   uint64_t lvl_cap = 0;
+  double *d_rows = nullptr;     // compacted statistic rows of the whole genome (epv_reduce_gathered_rows)
+  uint64_t rows_cap = 0;
   uint8_t *d_stage = nullptr;   // packed-column staging for the halo exchange (grown on demand)
   uint64_t stage_cap = 0;
   EpvIndepConst *d_indep = nullptr;  // [N] constants of the site-independent model
@@ -99,7 +101,7 @@ void free_paths(epv_ctx *c) {
   dfree(c->S.meta); dfree(c->S.jumps); dfree(c->S.sel); dfree(c->S.tri);
   dfree(c->S.prop_llr); dfree(c->S.prop_flag); dfree(c->S.prop_states); dfree(c->S.tasks);
   dfree(c->d_partial[0]); dfree(c->d_partial[1]);
-  c->partial_cap = 0;
+  c->partial_cap[0] = c->partial_cap[1] = 0;
   c->have_paths = c->have_reset = false;
 }
 
@@ -157,15 +159,25 @@ int plan_mh(epv_ctx *c) {
   return EPV_OK;
 }
 
+// the two ping-pong buffers of the canonical tree reduction, sized in DOUBLES for the launch
+// that uses them: level 0 holds one row per block, level 1 one row per 256 blocks
+int ensure_partial_doubles(epv_ctx *c, uint64_t need0, uint64_t need1) {
+  if (c->partial_cap[0] >= need0 && c->partial_cap[1] >= need1) return EPV_OK;
+  need0 = std::max(need0, c->partial_cap[0]);
+  need1 = std::max(need1, c->partial_cap[1]);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  dfree(c->d_partial[0]); dfree(c->d_partial[1]);
+  c->partial_cap[0] = c->partial_cap[1] = 0;
+  HIP_TRY(c, hipMalloc(&c->d_partial[0], need0 * sizeof(double)));
+  HIP_TRY(c, hipMalloc(&c->d_partial[1], need1 * sizeof(double)));
+  c->partial_cap[0] = need0;
+  c->partial_cap[1] = need1;
+  return EPV_OK;
+}
 int ensure_partials(epv_ctx *c, uint64_t nb_min = 0) {
   const uint64_t nb = std::max<uint64_t>((c->S.n + 255u) / 256u, nb_min);
   const uint64_t V = (uint64_t)c->S.B * 16u;
-  if (c->partial_cap >= nb * V) return EPV_OK;
-  dfree(c->d_partial[0]); dfree(c->d_partial[1]);
-  HIP_TRY(c, hipMalloc(&c->d_partial[0], nb * V * sizeof(double)));
-  HIP_TRY(c, hipMalloc(&c->d_partial[1], ((nb + 255u) / 256u) * V * sizeof(double)));
-  c->partial_cap = nb * V;
-  return EPV_OK;
+  return ensure_partial_doubles(c, nb * V, ((nb + 255u) / 256u) * V);
 }
 
 // Range of local sites a colour phase may update, and the owned range that statistics
@@ -330,7 +342,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl);
+  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->stream);
@@ -599,9 +611,9 @@ int indep_stats(epv_ctx *c, const double *rates, uint32_t what, double *J, doubl
   size_t lds = (size_t)c->S.N * threads * 5u * sizeof(double);
   if (lds > 60u * 1024u) { threads = 64u; lds = (size_t)c->S.N * threads * 5u * sizeof(double); }
   const uint64_t nb = (c->S.n + threads - 1u) / threads;
-  // the tree-reduction buffers are shared with the 8-context statistics (16 columns per
-  // branch and 256 sites per block there, so they are large enough for both shapes)
-  int rc = ensure_partials(c);
+  // the tree-reduction buffers are shared with the 8-context statistics but sized for THIS
+  // launch shape: nb rows of V16 doubles at level 0, ceil(nb/256) rows at level 1
+  int rc = ensure_partial_doubles(c, nb * V16, ((nb + 255u) / 256u) * V16);
   if (rc) return rc;
   if (lds > 150u * 1024u) return fail(c, EPV_ERR_ARG, "tree too large for the site-independent kernels");
   if (lds > 60u * 1024u &&
@@ -849,6 +861,21 @@ EPV_API int epv_dev_alloc(epv_ctx *c, uint64_t bytes, void **p) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMalloc(p, bytes));
   HIP_TRY(c, hipMemset(*p, 0, bytes));
+  HIP_TRY(c, hipDeviceSynchronize());   // the contexts' streams do not wait for the null stream
+  return EPV_OK;
+}
+// small host <-> device copies into / out of such buffers (e.g. the accept count a shard appends
+// to its statistic rows so that ONE all-gather carries everything)
+EPV_API int epv_dev_write(epv_ctx *c, void *d_dst, const void *src, uint64_t bytes) {
+  if (!c || !d_dst || !src) return EPV_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+  return EPV_OK;
+}
+EPV_API int epv_dev_read(epv_ctx *c, void *dst, const void *d_src, uint64_t bytes) {
+  if (!c || !dst || !d_src) return EPV_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
   return EPV_OK;
 }
 EPV_API int epv_dev_free(epv_ctx *c, void *p) {
@@ -860,7 +887,7 @@ EPV_API int epv_dev_free(epv_ctx *c, void *p) {
 
 EPV_API int epv_run_mcmc_blocks(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint64_t seed,
                                 uint32_t sweep_base, double *d_blocks, uint64_t nb_total,
-                                uint64_t block_offset, uint64_t *n_accepted) {
+                                int64_t block_offset, uint64_t *n_accepted) {
   int rc = check_ready(c, true);
   if (rc) return rc;
   if (!d_blocks || batch == 0) return fail(c, EPV_ERR_ARG, "bad run_mcmc_blocks arguments");
@@ -869,7 +896,10 @@ EPV_API int epv_run_mcmc_blocks(epv_ctx *c, uint64_t burn_in, uint64_t batch, ui
   uint64_t own_lo = 0, own_hi = 0;
   owned_range(c, &own_lo, &own_hi);
   const uint64_t blk_lo = own_lo / 256u, blk_hi = own_hi / 256u;
-  if (block_offset + blk_hi >= nb_total) return fail(c, EPV_ERR_ARG, "owned blocks exceed the group's block buffer");
+  // local block 0 may lie left of the buffer (a halo in front of the owned columns); the OWNED blocks must be inside
+  if (block_offset + (int64_t)blk_lo < 0 || block_offset + (int64_t)blk_hi >= (int64_t)nb_total)
+    return fail(c, EPV_ERR_ARG, "owned blocks exceed the group's block buffer");
+  if ((c->S.g0 & 255u) != 0u) return fail(c, EPV_ERR_ARG, "the shard must start on a 256-site block of the genome");
   uint32_t sweep = sweep_base;
   for (uint64_t w = 0; w < burn_in; ++w, ++sweep) {
     for (int colour = 0; colour < 3; ++colour)
@@ -884,7 +914,7 @@ EPV_API int epv_run_mcmc_blocks(epv_ctx *c, uint64_t burn_in, uint64_t batch, ui
     ++c->n_sweeps;
     hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)(blk_hi - blk_lo + 1u), c->S.B), dim3(256),
                        const_lds_bytes(c->S.N), c->stream, c->S, own_lo, own_hi, blk_lo,
-                       d_blocks + (w * nb_total + block_offset + blk_lo) * V);
+                       d_blocks + (w * nb_total + (uint64_t)(block_offset + (int64_t)blk_lo)) * V);
   }
   HIP_TRY(c, hipGetLastError());
   return finish_mcmc(c, n_accepted, base);  // synchronises the stream
@@ -934,6 +964,93 @@ EPV_API int epv_reduce_blocks(epv_ctx *c, const double *d_blocks, uint64_t nb_to
       D[b * 8 + k] = jd[b * 16 + 8 + k] / nb;
     }
   return EPV_OK;
+}
+
+// ---- statistics of a genome sharded over several GPUs: every GPU turns the level-0 partials
+// of its blocks into ROWS of row_blocks (a power of two) blocks, the rows of all GPUs are
+// all-gathered (RCCL; the caller's business), and the last stage sums the rows of the whole
+// genome -- the same balanced tree as the one-context reduction, so J and D keep their bits
+EPV_API int epv_blocks_to_rows(epv_ctx *c, const double *d_blocks, uint64_t nb_total, uint64_t batch,
+                               uint32_t row_blocks, double *d_rows) {
+  if (!c || !d_blocks || !d_rows || !nb_total || !batch) return EPV_ERR_ARG;
+  if (!c->have_tree) return fail(c, EPV_ERR_STATE, "epv_set_tree must come first");
+  if (row_blocks == 0 || (row_blocks & (row_blocks - 1u))) return fail(c, EPV_ERR_ARG, "row_blocks must be a power of two");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t V = c->S.B * 16u;
+  const uint64_t n_rows = (nb_total + row_blocks - 1u) / row_blocks;
+  if (n_rows > 65535u || batch > 65535u) return fail(c, EPV_ERR_ARG, "too many rows or batch sweeps for one launch");
+  // in: [w][block][V]   out: [row][w][V] (a GPU's rows are one contiguous piece of the gathered buffer)
+  hipLaunchKernelGGL(epv_rowsum_kernel, dim3((V + 255u) / 256u, (unsigned)n_rows, (unsigned)batch), dim3(256), 0,
+                     c->stream, d_blocks, nb_total, V, (uint64_t)row_blocks, (uint64_t)V, nb_total * V, d_rows,
+                     batch * V, (uint64_t)V);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EPV_OK;
+}
+
+EPV_API int epv_reduce_rows(epv_ctx *c, const double *d_rows, uint64_t n_rows, uint64_t batch, int average,
+                            double *J, double *D) {
+  if (!c || !d_rows || !J || !D || !n_rows || !batch) return EPV_ERR_ARG;
+  if (!c->have_tree) return fail(c, EPV_ERR_STATE, "epv_set_tree must come first");
+  if (batch > 65535u) return fail(c, EPV_ERR_ARG, "too many batch sweeps for one launch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t V = c->S.B * 16u;
+  if (batch * V > c->lvl_cap) {
+    dfree(c->d_lvl);
+    c->lvl_cap = 0;
+    HIP_TRY(c, hipMalloc(&c->d_lvl, batch * V * sizeof(double)));
+    c->lvl_cap = batch * V;
+  }
+  // per batch sweep the total over all rows (zero padded to a power of two), then the
+  // sequential accumulation over the sweeps exactly as run_mcmc adds them
+  hipLaunchKernelGGL(epv_rowsum_kernel, dim3((V + 255u) / 256u, 1u, (unsigned)batch), dim3(256), 0, c->stream,
+                     d_rows, n_rows, V, (uint64_t)0, batch * V, (uint64_t)V, c->d_lvl, (uint64_t)0, (uint64_t)V);
+  hipLaunchKernelGGL(epv_accumulate_seq_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream, c->d_jd_acc,
+                     c->d_lvl, V, batch, (uint64_t)V);
+  HIP_TRY(c, hipGetLastError());
+  std::vector<double> jd(V);
+  HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_jd_acc, V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const double nb = average ? (double)batch : 1.0;
+  for (uint32_t b = 0; b < c->S.B; ++b)
+    for (int k = 0; k < 8; ++k) {
+      J[b * 8 + k] = jd[b * 16 + k] / nb;
+      D[b * 8 + k] = jd[b * 16 + 8 + k] / nb;
+    }
+  return EPV_OK;
+}
+
+// the same on the buffer an all-gather of equally sized pieces leaves behind:
+// d_gathered[rank][max_rows][batch][V], of which the first rows_per_rank[rank] rows count
+EPV_API int epv_reduce_gathered_rows(epv_ctx *c, const double *d_gathered, uint32_t world, uint64_t max_rows,
+                                     uint64_t piece_doubles, const uint64_t *rows_per_rank, uint64_t batch,
+                                     int average, double *J, double *D) {
+  if (!c || !d_gathered || !world || !max_rows || !rows_per_rank || !batch) return EPV_ERR_ARG;
+  if (!c->have_tree) return fail(c, EPV_ERR_STATE, "epv_set_tree must come first");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t V = (uint64_t)c->S.B * 16u, row = batch * V;
+  if (piece_doubles == 0) piece_doubles = max_rows * row;
+  if (piece_doubles < max_rows * row) return fail(c, EPV_ERR_ARG, "piece_doubles smaller than max_rows rows");
+  uint64_t total = 0;
+  for (uint32_t r = 0; r < world; ++r) {
+    if (rows_per_rank[r] > max_rows) return fail(c, EPV_ERR_ARG, "rows_per_rank exceeds max_rows");
+    total += rows_per_rank[r];
+  }
+  if (!total) return fail(c, EPV_ERR_ARG, "no rows");
+  if (total * row > c->rows_cap) {
+    dfree(c->d_rows);
+    c->rows_cap = 0;
+    HIP_TRY(c, hipMalloc(&c->d_rows, total * row * sizeof(double)));
+    c->rows_cap = total * row;
+  }
+  uint64_t at = 0;
+  for (uint32_t r = 0; r < world; ++r) {
+    if (rows_per_rank[r])
+      HIP_TRY(c, hipMemcpyAsync(c->d_rows + at * row, d_gathered + (uint64_t)r * piece_doubles,
+                                rows_per_rank[r] * row * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    at += rows_per_rank[r];
+  }
+  return epv_reduce_rows(c, c->d_rows, total, batch, average, J, D);
 }
 
 EPV_API int epv_run_mcmc(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint64_t seed,
@@ -1082,6 +1199,34 @@ EPV_API int epv_copy_columns(epv_ctx *src, uint64_t src_first, uint64_t count, e
   HIP_TRY(dst, hipStreamSynchronize(dst->stream));
   return EPV_OK;
 }
+
+// the same with the packed columns staying in DEVICE memory of the context's GPU (a buffer the
+// caller hands to RCCL): nothing passes through the host
+EPV_API int epv_pack_columns_dev(epv_ctx *c, uint64_t first, uint64_t count, void *d_packed) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (first + count > c->S.n || !d_packed) return fail(c, EPV_ERR_ARG, "bad column range");
+  if (count == 0) return EPV_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(epv_pack_columns_kernel, dim3((unsigned)count), dim3(64), 0, c->stream, c->S,
+                     first, count, static_cast<uint8_t *>(d_packed));
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EPV_OK;
+}
+EPV_API int epv_unpack_columns_dev(epv_ctx *c, uint64_t first, uint64_t count, const void *d_packed) {
+  int rc = check_ready(c, false);
+  if (rc) return rc;
+  if (first + count > c->S.n || !d_packed) return fail(c, EPV_ERR_ARG, "bad column range");
+  if (count == 0) return EPV_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(epv_unpack_columns_kernel, dim3((unsigned)count), dim3(64), 0, c->stream, c->S,
+                     first, count, static_cast<const uint8_t *>(d_packed));
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return EPV_OK;
+}
+EPV_API int epv_device_of(const epv_ctx *c) { return c ? c->device : -1; }
 
 EPV_API int epv_put_columns(epv_ctx *c, uint64_t first, uint64_t count, const void *packed) {
   int rc = check_ready(c, false);

@@ -1285,6 +1285,43 @@ __global__ __launch_bounds__(256) void epv_tree_reduce_kernel(const double *in, 
         (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
 }
 
+// Generic piece of the canonical balanced-binary-tree reduction: out(r, z, c) = the balanced
+// pairwise sum of the G consecutive input rows r*G .. r*G+G-1 (rows >= m read as zero) of
+// value column c in slice z.  G is any power of two -- or, with G = 0, "all m rows, zero padded
+// to the next power of two".  One lane per output element runs the binary-counter form of
+// pairwise summation (a stack of at most 40 partial sums): every node of the tree is
+// left + right with aligned power-of-two subtrees, i.e. exactly the sums the 256-ary levels of
+// epv_tree_reduce_kernel and the oracle's recursive tree_sum form, so any chain of such stages
+// (256-site blocks -> rows of 2^g blocks -> all-gather over the GPUs -> total) gives the bits of
+// the one-context reduction.  Consecutive lanes take consecutive columns (coalesced).
+__global__ __launch_bounds__(256) void epv_rowsum_kernel(const double *in, uint64_t m, uint32_t V,
+                                                         uint64_t G, uint64_t in_row_stride,
+                                                         uint64_t in_z_stride, double *out,
+                                                         uint64_t out_row_stride, uint64_t out_z_stride) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= V) return;
+  const uint64_t r = blockIdx.y, z = blockIdx.z;
+  const uint64_t lo = G ? r * G : 0u;
+  uint64_t hi = G ? lo + G : m;
+  if (hi > m) hi = m;
+  const double *p = in + z * in_z_stride + c;
+  double st[40];   // 2^40 rows
+  int sp = 0;
+  for (uint64_t i = lo; i < hi; ++i) {
+    double x = p[i * in_row_stride];
+    for (uint64_t k = i - lo; k & 1u; k >>= 1) x = st[--sp] + x;
+    st[sp++] = x;
+  }
+  // rows beyond m are zeros: a partial subtree plus zeros is the subtree itself, so the stack
+  // collapses from the smallest block upwards (left + right at every node)
+  double x = 0.0;
+  if (sp > 0) {
+    x = st[--sp];
+    while (sp > 0) x = st[--sp] + x;
+  }
+  out[r * out_row_stride + z * out_z_stride + c] = x;
+}
+
 // acc[i] = ((0 + t_0[i]) + t_1[i]) + ... : the same sequence of additions as `batch` calls of
 // the kernel below on a zeroed accumulator
 __global__ void epv_accumulate_seq_kernel(double *acc, const double *tot, uint32_t count, uint64_t batch,

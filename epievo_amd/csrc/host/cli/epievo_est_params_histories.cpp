@@ -3,6 +3,10 @@
 // positionals, same param / Newick / local_paths formats, same per-iteration outputs and
 // -v TSV line.  The E-step (reset + run_mcmc) and scale_jump_times run on the GPU; the
 // O(8) M-step runs on the host.
+// One extension: -g/--gpus <list> (or the environment variable EPV_DEVICES) names the GPUs of
+// the node to shard the sites over -- "all", or HIP device ids "0,1,2,3" -- with RCCL between
+// them (epv_sampler.hpp); results do not depend on the list.  A list with repeats ("0,0,0,0")
+// rehearses a multi-GPU run on fewer GPUs.
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -28,7 +32,7 @@ static string strip_path(const string &full) {
 int main(int argc, const char **argv) {
   try {
     bool VERBOSE = false, single_branch = false, optimize_branches = false;
-    string outfile, param_file_updated, tree_file, treefile_updated;
+    string outfile, param_file_updated, tree_file, treefile_updated, gpu_list;
     size_t iteration = 10, batch = 10, burnin = 10;
     size_t rng_seed = std::numeric_limits<size_t>::max();
     static const double param_tol = 1e-10;
@@ -45,6 +49,8 @@ int main(int argc, const char **argv) {
     opt_parse.add_opt("single_branch", 'T', "pairwise process (assumes no tree)", false, single_branch);
     opt_parse.add_opt("branch", 'b', "optimize branch lengths", false, optimize_branches);
     opt_parse.add_opt("verbose", 'v', "print more run info", false, VERBOSE);
+    opt_parse.add_opt("gpus", 'g', "GPUs to shard the sites over: all | 0,1,.. (default: EPV_DEVICES or 0)", false,
+                      gpu_list);
     vector<string> leftover_args;
     opt_parse.parse(argc, argv, leftover_args);
     if (argc == 1 || opt_parse.help_requested()) {
@@ -84,10 +90,21 @@ int main(int argc, const char **argv) {
     }
     if (th.n_nodes() != paths.n_nodes)
       throw std::runtime_error("tree and paths file have different numbers of nodes");
+    // The reference compares nothing here: branch lengths come from the tree, each Path keeps the
+    // tot_time of the file, and scale_jump_times (ParamEstimation.cpp:369-380) brings the two
+    // together at the end of the first iteration.  epievo_initialization without -b writes
+    // rate-scaled tot_times next to an unscaled tree, so a mismatch is an ordinary input.  The
+    // device keeps one length per branch, hence the same rescaling is applied at load time.
     for (int b = 1; b < th.n_nodes(); ++b)
-      if (tot_times[b] != th.branches[b])
-        throw std::runtime_error("paths file tot_time differs from the tree's branch length at node " +
-                                 th.node_names[b]);
+      if (tot_times[b] != th.branches[b]) {
+        const double scale = th.branches[b] / tot_times[b];
+        const uint64_t n = paths.n_sites;
+        for (uint64_t k = paths.offsets[(uint64_t)(b - 1) * n]; k < paths.offsets[(uint64_t)b * n]; ++k)
+          paths.jumps[k] *= scale;
+        if (VERBOSE)
+          cerr << "[RESCALING PATHS OF NODE " << th.node_names[b] << ": tot_time " << tot_times[b]
+               << " -> branch length " << th.branches[b] << "]" << endl;
+      }
 
     if (rng_seed == std::numeric_limits<size_t>::max()) {
       std::random_device rd;
@@ -100,10 +117,15 @@ int main(int argc, const char **argv) {
            << "\t" << the_model.baseline[3] << endl;
     }
 
-    epv::SingleSiteSampler mcmc(burnin, batch);
+    epv::SingleSiteSampler mcmc(burnin, batch,
+                                gpu_list.empty() ? epv::devices_from_env() : epv::parse_device_list(gpu_list));
     for (size_t itr = 0; itr < iteration; itr++) {
-      if (itr == 0) mcmc.reset(the_model, th, paths);
-      else mcmc.reset(the_model);
+      if (itr == 0) {
+        mcmc.reset(the_model, th, paths);
+        if (VERBOSE) cerr << "[GPU LAYOUT: " << mcmc.layout() << "]" << endl;
+      } else {
+        mcmc.reset(the_model);
+      }
 
       double acceptance_rate;
       vector<vector<double>> J_accum, D_accum;

@@ -3,16 +3,21 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <thread>
 
 #include "epievo_mi355x.h"
+#include "epievo_mi355x_comm.h"
 
 namespace epv {
 
 namespace {
-const uint64_t kHalo = 512, kBlock = 256;   // internal halo columns; reduction block (sites)
+const uint64_t kBlock = 256;   // sites per level-0 block of the statistics tree
+const uint32_t kMaxCap = 127;
+
+uint64_t round_to(double x, uint64_t unit) { return (uint64_t)(x / (double)unit + 0.5) * unit; }
 
 // sites [lo, hi) of node-major flat paths
 FlatPaths slice_sites(const FlatPaths &p, uint64_t lo, uint64_t hi) {
@@ -56,51 +61,111 @@ FlatPaths concat_sites(const std::vector<FlatPaths> &parts) {
 }
 }  // namespace
 
+std::vector<int> parse_device_list(const std::string &spec) {
+  std::vector<int> out;
+  if (spec.empty()) return {0};
+  if (spec == "all") {
+    // every GPU HIP shows; counted by probing contexts so that this file needs no HIP header
+    for (int d = 0; d < 64; ++d) {
+      epv_ctx *c = epv_create(d);
+      if (!c) break;
+      epv_destroy(c);
+      out.push_back(d);
+    }
+    if (out.empty()) throw std::runtime_error("no HIP device found (this build has no CPU fallback)");
+    return out;
+  }
+  std::stringstream ss(spec);
+  std::string tok;
+  while (std::getline(ss, tok, ',')) {
+    char *end = nullptr;
+    const long v = std::strtol(tok.c_str(), &end, 10);
+    if (tok.empty() || *end != '\0' || v < 0) throw std::runtime_error("bad device list: " + spec);
+    out.push_back((int)v);
+  }
+  if (out.empty()) throw std::runtime_error("bad device list: " + spec);
+  return out;
+}
+
+std::vector<int> devices_from_env() {
+  const char *e = std::getenv("EPV_DEVICES");
+  return parse_device_list(e ? e : "");
+}
+
 SingleSiteSampler::SingleSiteSampler(size_t n_burn_in, size_t n_batch, int device, uint32_t capacity)
-    : SAMPLE_ROOT(false), burn_in(n_burn_in), batch(n_batch), ctx_(epv_create(device)), device_(device),
+    : SingleSiteSampler(n_burn_in, n_batch, std::vector<int>(1, device), capacity) {}
+
+SingleSiteSampler::SingleSiteSampler(size_t n_burn_in, size_t n_batch, const std::vector<int> &devices,
+                                     uint32_t capacity)
+    : SAMPLE_ROOT(false), burn_in(n_burn_in), batch(n_batch), ctx_(nullptr), devices_(devices),
       capacity_(capacity) {
+  if (devices_.empty()) devices_.push_back(0);
+  ctx_ = epv_create(devices_[0]);
   if (!ctx_)
-    throw std::runtime_error("cannot open HIP device " + std::to_string(device) +
+    throw std::runtime_error("cannot open HIP device " + std::to_string(devices_[0]) +
                              " (this build has no CPU fallback)");
   if (const char *e = std::getenv("EPV_CONTEXTS_PER_GPU")) contexts_wanted_ = std::max(1, std::atoi(e));
-  group_.push_back(ctx_);
+  if (const char *e = std::getenv("EPV_ROW_BLOCKS")) {
+    const int v = std::atoi(e);
+    if (v < 1 || v > 4096 || (v & (v - 1))) throw std::runtime_error("EPV_ROW_BLOCKS must be a power of two");
+    row_blocks_ = (uint32_t)v;
+  }
+  if (const char *e = std::getenv("EPV_FORCE_COMM")) force_comm_ = std::atoi(e) != 0;
 }
 
 SingleSiteSampler::~SingleSiteSampler() {
-  drop_group();
+  drop_parts();
   epv_destroy(ctx_);
 }
 
-void SingleSiteSampler::drop_group() {
-  if (d_blocks_) { epv_dev_free(ctx_, d_blocks_); d_blocks_ = nullptr; blocks_batch_ = 0; }
-  for (size_t j = 1; j < group_.size(); ++j) epv_destroy(group_[j]);
-  group_.assign(1, ctx_);
-  lo_.clear(); a_.clear(); b_.clear(); hi_.clear();
+void SingleSiteSampler::free_stat_buffers() {
+  for (Slot &s : slots_) {
+    epv_ctx *c = parts_[s.part0].ctx;
+    if (s.d_blocks) epv_dev_free(c, s.d_blocks);
+    if (s.d_rows) epv_dev_free(c, s.d_rows);
+    if (s.d_gather) epv_dev_free(c, s.d_gather);
+    s.d_blocks = s.d_rows = s.d_gather = nullptr;
+  }
+  stat_batch_ = 0;
+}
+
+void SingleSiteSampler::drop_parts() {
+  free_stat_buffers();
+  for (Slot &s : slots_) {
+    epv_ctx *c = parts_[s.part0].ctx;
+    for (void *&p : s.d_halo) { if (p) epv_dev_free(c, p); p = nullptr; }
+    if (s.comm) epv_comm_destroy(s.comm);
+    s.comm = nullptr;
+  }
+  for (Part &p : parts_) if (p.ctx != ctx_) epv_destroy(p.ctx);
+  parts_.clear();
+  slots_.clear();
+}
+
+bool SingleSiteSampler::uses_rccl() const {
+  return !slots_.empty() && slots_[0].comm && epv_comm_is_rccl(slots_[0].comm);
+}
+
+std::string SingleSiteSampler::layout() const {
+  std::ostringstream o;
+  if (!sharded()) { o << "1 context on device " << devices_[0]; return o.str(); }
+  o << slots_.size() << " GPU slot(s) x up to " << contexts_wanted_ << " context(s) = " << parts_.size()
+    << " parts, halo " << halo_ << " columns";
+  if (slots_[0].comm)
+    o << ", statistics rows of " << kBlock * row_blocks_ << " sites, exchange over "
+      << (uses_rccl() ? "RCCL" : "the loopback transport");
+  o << "; devices";
+  for (const Slot &s : slots_) o << " " << s.device;
+  return o.str();
 }
 
 void SingleSiteSampler::check_on(epv_ctx *c, int rc, const char *what) {
   if (rc != EPV_OK) throw std::runtime_error(std::string(what) + ": " + epv_last_error(c));
 }
-
-// before every reset of a group: equal jump-slot widths (an overflow may have widened one
-// context), each context's edge columns into its neighbour's halo, halos marked fresh
-void SingleSiteSampler::refresh_group() {
-  const size_t k = group_.size();
-  uint32_t cap = 0;
-  for (epv_ctx *c : group_) { uint32_t v = 0; check_on(c, epv_get_capacity(c, &v), "epv_get_capacity"); cap = std::max(cap, v); }
-  for (epv_ctx *c : group_) check_on(c, epv_set_capacity(c, cap), "epv_set_capacity");
-  for (size_t j = 0; j + 1 < k; ++j) {
-    epv_ctx *L = group_[j], *R = group_[j + 1];
-    check_on(R, epv_copy_columns(L, b_[j] - kHalo - lo_[j], kHalo, R, 0), "epv_copy_columns");
-    check_on(L, epv_copy_columns(R, kHalo, kHalo, L, b_[j] - lo_[j]), "epv_copy_columns");
-  }
-  for (size_t j = 0; j < k; ++j)
-    check_on(group_[j], epv_set_halo(group_[j], j == 0 ? 0 : kHalo, j + 1 == k ? 0 : kHalo), "epv_set_halo");
+void SingleSiteSampler::check_comm(epv_comm *c, int rc, const char *what) {
+  if (rc != EPV_OK) throw std::runtime_error(std::string(what) + ": " + epv_comm_last_error(c));
 }
-
-void SingleSiteSampler::check(int rc, const char *what) {
-  if (rc != EPV_OK) throw std::runtime_error(std::string(what) + ": " + epv_last_error(ctx_));
-}
+void SingleSiteSampler::check(int rc, const char *what) { check_on(ctx_, rc, what); }
 
 // after an MCMC call: an overflow leaves a valid chain and complete outputs (the over-long
 // proposals were rejected), so widen the jump slots for the following calls -- what the
@@ -108,9 +173,9 @@ void SingleSiteSampler::check(int rc, const char *what) {
 void SingleSiteSampler::check_mcmc(int rc, const char *what) {
   if (rc == EPV_ERR_CAPACITY) {
     uint32_t cap = 0;
-    if (epv_get_capacity(ctx_, &cap) == EPV_OK && cap < 127u) {
+    if (epv_get_capacity(ctx_, &cap) == EPV_OK && cap < kMaxCap) {
       const std::string msg = epv_last_error(ctx_);
-      check(epv_set_capacity(ctx_, cap * 2u > 127u ? 127u : cap * 2u), "epv_set_capacity");
+      check(epv_set_capacity(ctx_, std::min(kMaxCap, cap * 2u)), "epv_set_capacity");
       capacity_events.push_back(std::string(what) + ": " + msg);
       return;
     }
@@ -118,14 +183,96 @@ void SingleSiteSampler::check_mcmc(int rc, const char *what) {
   check(rc, what);
 }
 
+void SingleSiteSampler::equalize_capacity() {
+  uint32_t cap = 0;
+  for (Part &p : parts_) { uint32_t v = 0; check_on(p.ctx, epv_get_capacity(p.ctx, &v), "epv_get_capacity"); cap = std::max(cap, v); }
+  for (Part &p : parts_) check_on(p.ctx, epv_set_capacity(p.ctx, cap), "epv_set_capacity");
+}
+
+// Before every reset of a sharded genome: equal jump-slot widths (an overflow may have widened
+// one part), each part's edge columns into its neighbour's halo -- a device-to-device copy
+// inside a GPU, one RCCL send/receive pair per GPU boundary -- and the halos marked fresh.
+void SingleSiteSampler::refresh_parts() {
+  const size_t P = parts_.size();
+  const uint64_t H = halo_;
+  equalize_capacity();
+  const uint64_t bytes = H * epv_column_bytes(parts_[0].ctx);
+  bool any_cross = false;
+  for (size_t p = 0; p + 1 < P; ++p) {
+    Part &L = parts_[p], &R = parts_[p + 1];
+    if (L.slot == R.slot) {
+      check_on(R.ctx, epv_copy_columns(L.ctx, L.b - H - L.lo, H, R.ctx, 0), "epv_copy_columns");
+      check_on(L.ctx, epv_copy_columns(R.ctx, H, H, L.ctx, L.b - L.lo), "epv_copy_columns");
+      continue;
+    }
+    any_cross = true;
+    for (Slot *s : {&slots_[L.slot], &slots_[R.slot]}) {
+      if (s->halo_bytes == bytes) continue;
+      epv_ctx *c = parts_[s->part0].ctx;
+      for (void *&q : s->d_halo) {
+        if (q) check_on(c, epv_dev_free(c, q), "epv_dev_free");
+        q = nullptr;
+        check_on(c, epv_dev_alloc(c, bytes, &q), "epv_dev_alloc");
+      }
+      s->halo_bytes = bytes;
+    }
+    check_on(L.ctx, epv_pack_columns_dev(L.ctx, L.b - H - L.lo, H, slots_[L.slot].d_halo[2]), "epv_pack_columns_dev");
+    check_on(R.ctx, epv_pack_columns_dev(R.ctx, H, H, slots_[R.slot].d_halo[0]), "epv_pack_columns_dev");
+  }
+  if (any_cross) {
+    const size_t G = slots_.size();
+    if (epv_comm_group_start() != EPV_OK) throw std::runtime_error("epv_comm_group_start failed");
+    for (size_t g = 0; g < G; ++g) {
+      Slot &s = slots_[g];
+      check_comm(s.comm, epv_comm_exchange(s.comm, s.d_halo[0], s.d_halo[1], g > 0 ? bytes : 0, s.d_halo[2],
+                                           s.d_halo[3], g + 1 < G ? bytes : 0), "epv_comm_exchange");
+    }
+    if (epv_comm_group_end() != EPV_OK) throw std::runtime_error("epv_comm_group_end failed (halo exchange)");
+    for (Slot &s : slots_) check_comm(s.comm, epv_comm_sync(s.comm), "epv_comm_sync");
+    for (size_t p = 0; p + 1 < P; ++p) {
+      Part &L = parts_[p], &R = parts_[p + 1];
+      if (L.slot == R.slot) continue;
+      check_on(L.ctx, epv_unpack_columns_dev(L.ctx, L.b - L.lo, H, slots_[L.slot].d_halo[3]), "epv_unpack_columns_dev");
+      check_on(R.ctx, epv_unpack_columns_dev(R.ctx, 0, H, slots_[R.slot].d_halo[1]), "epv_unpack_columns_dev");
+    }
+  }
+  for (size_t p = 0; p < P; ++p)
+    check_on(parts_[p].ctx, epv_set_halo(parts_[p].ctx, p == 0 ? 0 : H, p + 1 == P ? 0 : H), "epv_set_halo");
+}
+
 void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &paths) {
   n_nodes_ = th.n_nodes();
   n_sites_ = paths.n_sites;
-  drop_group();
+  drop_parts();
   const uint64_t n = paths.n_sites;
-  size_t k = (size_t)contexts_wanted_;
-  while (k > 1 && n < k * (2 * kHalo + 2 * kBlock)) --k;   // every context must own more than its halos
-  if (k == 1) {
+  // a halo that lasts one whole run_mcmc (two columns per colour phase), in whole blocks
+  const uint64_t H = std::max<uint64_t>(kBlock, (6 * (uint64_t)(burn_in + batch) + 2 + kBlock - 1) / kBlock * kBlock);
+  const uint64_t min_part = 2 * H + 2 * kBlock;     // every part must own more than its halos
+  const uint64_t RS = kBlock * row_blocks_;
+  // slots: as many of the requested GPUs as the genome can feed, cut on whole statistics rows
+  size_t G = devices_.size();
+  std::vector<uint64_t> cut;
+  for (;; --G) {
+    cut.assign(G + 1, 0);
+    cut[G] = n;
+    bool ok = true;
+    for (size_t g = 1; g < G; ++g) cut[g] = round_to((double)g * (double)n / (double)G, RS);
+    for (size_t g = 0; g < G && ok; ++g) ok = cut[g + 1] > cut[g] && cut[g + 1] - cut[g] >= min_part;
+    if (ok || G == 1) break;
+  }
+  struct Piece { size_t slot; uint64_t a, b; };
+  std::vector<Piece> pieces;
+  for (size_t g = 0; g < G; ++g) {
+    const uint64_t len = cut[g + 1] - cut[g];
+    size_t k = (size_t)contexts_wanted_;
+    while (k > 1 && len < k * min_part) --k;
+    for (size_t j = 0; j < k; ++j) {
+      const uint64_t a = j == 0 ? cut[g] : cut[g] + round_to((double)j * (double)len / (double)k, kBlock);
+      const uint64_t b = j + 1 == k ? cut[g + 1] : cut[g] + round_to((double)(j + 1) * (double)len / (double)k, kBlock);
+      pieces.push_back({g, a, b});
+    }
+  }
+  if (pieces.size() == 1 && !force_comm_) {
     check(epv_set_tree(ctx_, th.n_nodes(), th.parent_ids.data(), th.subtree_sizes.data(),
                        th.branches.data()), "epv_set_tree");
     check(epv_upload_paths(ctx_, paths.n_sites, paths.init.data(), paths.offsets.data(),
@@ -137,29 +284,53 @@ void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &p
   if (cap == 0) {   // the library's default rule, evaluated once for the whole genome
     uint64_t maxj = 0;
     for (size_t e = 0; e + 1 < paths.offsets.size(); ++e) maxj = std::max(maxj, paths.offsets[e + 1] - paths.offsets[e]);
-    cap = (uint32_t)std::min<uint64_t>(127, std::max<uint64_t>(16, 2 * maxj + 8));
+    cap = (uint32_t)std::min<uint64_t>(kMaxCap, std::max<uint64_t>(16, 2 * maxj + 8));
   }
-  for (size_t j = 1; j < k; ++j) {
-    epv_ctx *c = epv_create(device_);
-    if (!c) throw std::runtime_error("cannot open a second context on HIP device " + std::to_string(device_));
-    group_.push_back(c);
+  halo_ = H;
+  slots_.resize(G);
+  for (size_t g = 0; g < G; ++g) {
+    slots_[g].device = devices_[g];
+    slots_[g].first = cut[g];
+    slots_[g].last = cut[g + 1];
+    slots_[g].n_blocks = (cut[g + 1] - cut[g] + kBlock - 1) / kBlock;
+    slots_[g].n_rows = (slots_[g].n_blocks + row_blocks_ - 1) / row_blocks_;
   }
-  for (size_t j = 0; j <= k; ++j) {   // cut points on whole reduction blocks
-    const uint64_t cut = j == 0 ? 0 : j == k ? n : (uint64_t)((double)j * (double)n / (double)k / kBlock + 0.5) * kBlock;
-    if (j < k) a_.push_back(cut);
-    if (j > 0) b_.push_back(cut);
-  }
-  for (size_t j = 0; j < k; ++j) {
-    lo_.push_back(a_[j] - (j > 0 ? kHalo : 0));
-    hi_.push_back(b_[j] + (j + 1 < k ? kHalo : 0));
-    epv_ctx *c = group_[j];
+  const size_t P = pieces.size();
+  for (size_t p = 0; p < P; ++p) {
+    Part q;
+    q.slot = pieces[p].slot;
+    q.a = pieces[p].a;
+    q.b = pieces[p].b;
+    q.lo = q.a - (p > 0 ? H : 0);
+    q.hi = q.b + (p + 1 < P ? H : 0);
+    if (p == 0) {
+      q.ctx = ctx_;
+    } else {
+      q.ctx = epv_create(slots_[q.slot].device);
+      if (!q.ctx)
+        throw std::runtime_error("cannot open a context on HIP device " + std::to_string(slots_[q.slot].device));
+    }
+    if (parts_.empty() || parts_.back().slot != q.slot) slots_[q.slot].part0 = parts_.size();
+    slots_[q.slot].part1 = parts_.size() + 1;
+    parts_.push_back(q);
+    epv_ctx *c = q.ctx;
     check_on(c, epv_set_tree(c, th.n_nodes(), th.parent_ids.data(), th.subtree_sizes.data(), th.branches.data()),
              "epv_set_tree");
-    const FlatPaths part = slice_sites(paths, lo_[j], hi_[j]);
+    const FlatPaths part = slice_sites(paths, q.lo, q.hi);
     const double dummy = 0.0;
     check_on(c, epv_upload_paths(c, part.n_sites, part.init.data(), part.offsets.data(),
-                                 part.jumps.empty() ? &dummy : part.jumps.data(), cap, lo_[j]), "epv_upload_paths");
+                                 part.jumps.empty() ? &dummy : part.jumps.data(), cap, q.lo), "epv_upload_paths");
     check_on(c, epv_set_global_length(c, n), "epv_set_global_length");
+  }
+  if (G > 1 || force_comm_) {
+    // one communicator rank per slot, all driven from this process: RCCL over the node's xGMI
+    // links when the devices are distinct, the loopback transport when they repeat
+    std::vector<int> devs(G);
+    std::vector<epv_comm *> comms(G, nullptr);
+    for (size_t g = 0; g < G; ++g) devs[g] = slots_[g].device;
+    if (epv_comm_init_all((int)G, devs.data(), comms.data()) != EPV_OK)
+      throw std::runtime_error("cannot set up the RCCL communicator over " + std::to_string(G) + " GPU slot(s)");
+    for (size_t g = 0; g < G; ++g) slots_[g].comm = comms[g];
   }
   reset(m);
 }
@@ -167,7 +338,7 @@ void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &p
 void SingleSiteSampler::init_paths_indep(const Model &m, const Tree &th, const std::vector<uint8_t> &root_seq,
                                          const std::vector<uint8_t> &leaf_seq, uint64_t seed) {
   if (root_seq.size() != leaf_seq.size()) throw std::runtime_error("sequences differ in length");
-  drop_group();   // epievo_sim_pairwise's path runs on one context
+  drop_parts();   // epievo_sim_pairwise's path runs on one context
   n_nodes_ = th.n_nodes();
   n_sites_ = root_seq.size();
   check(epv_set_tree(ctx_, th.n_nodes(), th.parent_ids.data(), th.subtree_sizes.data(),
@@ -179,9 +350,31 @@ void SingleSiteSampler::init_paths_indep(const Model &m, const Tree &th, const s
 }
 
 void SingleSiteSampler::reset(const Model &m) {
-  for (epv_ctx *c : group_) check_on(c, epv_set_model(c, m.rates.data(), m.T.data()), "epv_set_model");
-  if (grouped()) refresh_group();
-  for (epv_ctx *c : group_) check_on(c, epv_reset(c), "epv_reset");
+  if (!sharded()) {
+    check(epv_set_model(ctx_, m.rates.data(), m.T.data()), "epv_set_model");
+    check(epv_reset(ctx_), "epv_reset");
+    return;
+  }
+  for (Part &p : parts_) check_on(p.ctx, epv_set_model(p.ctx, m.rates.data(), m.T.data()), "epv_set_model");
+  refresh_parts();
+  for (Part &p : parts_) check_on(p.ctx, epv_reset(p.ctx), "epv_reset");
+}
+
+void SingleSiteSampler::ensure_stat_buffers() {
+  if (stat_batch_ >= batch && slots_[0].d_blocks) return;
+  free_stat_buffers();
+  const uint64_t V = ((uint64_t)n_nodes_ - 1) * 16;
+  max_rows_ = 0;
+  for (Slot &s : slots_) max_rows_ = std::max(max_rows_, s.n_rows);
+  for (Slot &s : slots_) {
+    epv_ctx *c = parts_[s.part0].ctx;
+    check_on(c, epv_dev_alloc(c, batch * s.n_blocks * V * sizeof(double), &s.d_blocks), "epv_dev_alloc");
+    if (s.comm) {
+      check_on(c, epv_dev_alloc(c, max_rows_ * batch * V * sizeof(double), &s.d_rows), "epv_dev_alloc");
+      check_on(c, epv_dev_alloc(c, slots_.size() * max_rows_ * batch * V * sizeof(double), &s.d_gather), "epv_dev_alloc");
+    }
+  }
+  stat_batch_ = batch;
 }
 
 void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
@@ -191,41 +384,61 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
   std::vector<double> Jf(B * 8), Df(B * 8);
   uint64_t n_acc = 0;
   const uint32_t base = (uint32_t)(em_iteration * (burn_in + batch));
-  if (!grouped()) {
+  if (!sharded()) {
     check_mcmc(epv_run_mcmc(ctx_, burn_in, batch, seed, base, Jf.data(), Df.data(), &n_acc), "epv_run_mcmc");
   } else {
-    const uint64_t nb_total = (n_sites_ + kBlock - 1) / kBlock, V = B * 16;
-    if (!d_blocks_ || blocks_batch_ < batch) {
-      if (d_blocks_) check(epv_dev_free(ctx_, d_blocks_), "epv_dev_free");
-      d_blocks_ = nullptr;
-      check(epv_dev_alloc(ctx_, batch * nb_total * V * sizeof(double), &d_blocks_), "epv_dev_alloc");
-      blocks_batch_ = batch;
-    }
-    // one host thread per context: their colour phases run concurrently on their own streams
-    const size_t k = group_.size();
-    std::vector<int> rcs(k, EPV_OK);
-    std::vector<uint64_t> acc(k, 0);
+    ensure_stat_buffers();
+    // one host thread per part: their colour phases run concurrently, each GPU on its own,
+    // the contexts of one GPU on their own streams
+    const size_t P = parts_.size();
+    std::vector<int> rcs(P, EPV_OK);
+    std::vector<uint64_t> acc(P, 0);
     std::vector<std::thread> th;
-    for (size_t j = 0; j < k; ++j)
-      th.emplace_back([&, j] {
-        rcs[j] = epv_run_mcmc_blocks(group_[j], burn_in, batch, seed, base, static_cast<double *>(d_blocks_),
-                                     nb_total, lo_[j] / kBlock, &acc[j]);
+    for (size_t p = 0; p < P; ++p)
+      th.emplace_back([&, p] {
+        const Part &q = parts_[p];
+        const Slot &s = slots_[q.slot];
+        rcs[p] = epv_run_mcmc_blocks(q.ctx, burn_in, batch, seed, base, static_cast<double *>(s.d_blocks),
+                                     s.n_blocks, ((int64_t)q.lo - (int64_t)s.first) / (int64_t)kBlock, &acc[p]);
       });
     for (std::thread &t : th) t.join();
-    for (size_t j = 0; j < k; ++j) {
-      if (rcs[j] == EPV_ERR_CAPACITY) {   // absorbed as in check_mcmc; refresh_group() evens the widths out
+    for (size_t p = 0; p < P; ++p) {
+      epv_ctx *c = parts_[p].ctx;
+      if (rcs[p] == EPV_ERR_CAPACITY) {   // absorbed as in check_mcmc; refresh_parts() evens the widths out
         uint32_t cap = 0;
-        if (epv_get_capacity(group_[j], &cap) == EPV_OK && cap < 127u) {
-          capacity_events.push_back(std::string("epv_run_mcmc_blocks: ") + epv_last_error(group_[j]));
-          check_on(group_[j], epv_set_capacity(group_[j], cap * 2u > 127u ? 127u : cap * 2u), "epv_set_capacity");
-          rcs[j] = EPV_OK;
+        if (epv_get_capacity(c, &cap) == EPV_OK && cap < kMaxCap) {
+          capacity_events.push_back(std::string("epv_run_mcmc_blocks: ") + epv_last_error(c));
+          check_on(c, epv_set_capacity(c, std::min(kMaxCap, cap * 2u)), "epv_set_capacity");
+          rcs[p] = EPV_OK;
         }
       }
-      check_on(group_[j], rcs[j], "epv_run_mcmc_blocks");
-      n_acc += acc[j];
+      check_on(c, rcs[p], "epv_run_mcmc_blocks");
+      n_acc += acc[p];
     }
-    check(epv_reduce_blocks(ctx_, static_cast<const double *>(d_blocks_), nb_total, batch, 1, Jf.data(), Df.data()),
-          "epv_reduce_blocks");
+    if (!slots_[0].comm) {
+      const Slot &s = slots_[0];
+      check(epv_reduce_blocks(ctx_, static_cast<const double *>(s.d_blocks), s.n_blocks, batch, 1, Jf.data(), Df.data()),
+            "epv_reduce_blocks");
+    } else {
+      // the one collective of an EM iteration: every GPU's rows of the statistics tree
+      const size_t G = slots_.size();
+      const uint64_t row_bytes = batch * B * 16 * sizeof(double);
+      for (Slot &s : slots_) {
+        epv_ctx *c = parts_[s.part0].ctx;
+        check_on(c, epv_blocks_to_rows(c, static_cast<const double *>(s.d_blocks), s.n_blocks, batch, row_blocks_,
+                                       static_cast<double *>(s.d_rows)), "epv_blocks_to_rows");
+      }
+      if (epv_comm_group_start() != EPV_OK) throw std::runtime_error("epv_comm_group_start failed");
+      for (Slot &s : slots_)
+        check_comm(s.comm, epv_comm_all_gather(s.comm, s.d_rows, s.d_gather, max_rows_ * row_bytes), "epv_comm_all_gather");
+      if (epv_comm_group_end() != EPV_OK) throw std::runtime_error("epv_comm_group_end failed (statistics all-gather)");
+      for (Slot &s : slots_) check_comm(s.comm, epv_comm_sync(s.comm), "epv_comm_sync");
+      std::vector<uint64_t> rows(G);
+      for (size_t g = 0; g < G; ++g) rows[g] = slots_[g].n_rows;
+      // every GPU now holds the same rows; the host M-step needs one copy of the totals
+      check(epv_reduce_gathered_rows(ctx_, static_cast<const double *>(slots_[0].d_gather), (uint32_t)G, max_rows_, 0,
+                                     rows.data(), batch, 1, Jf.data(), Df.data()), "epv_reduce_gathered_rows");
+    }
   }
   J.assign(n_nodes_, {});
   D.assign(n_nodes_, {});
@@ -238,40 +451,58 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
 
 size_t SingleSiteSampler::sweeps(size_t n, uint64_t seed, uint32_t sweep_base) {
   uint64_t n_acc = 0;
-  if (!grouped()) {
+  if (!sharded()) {
     check_mcmc(epv_sweep(ctx_, n, seed, sweep_base, &n_acc), "epv_sweep");
     return n_acc;
   }
-  // a group can run as many sweeps as its internal halos last, then they are refreshed
+  // a sharded genome can run as many sweeps as its halos last, then they are refreshed
   size_t done = 0;
   while (done < n) {
     uint64_t left = ~0ull;
-    for (epv_ctx *c : group_) { uint64_t v = 0; check_on(c, epv_halo_phases_left(c, &v), "epv_halo_phases_left"); left = std::min(left, v); }
+    for (Part &p : parts_) { uint64_t v = 0; check_on(p.ctx, epv_halo_phases_left(p.ctx, &v), "epv_halo_phases_left"); left = std::min(left, v); }
     const size_t kk = std::min<size_t>(n - done, (size_t)(left / 3));
     if (kk == 0) {
-      refresh_group();
-      for (epv_ctx *c : group_) check_on(c, epv_reset(c), "epv_reset");
+      refresh_parts();
+      for (Part &p : parts_) check_on(p.ctx, epv_reset(p.ctx), "epv_reset");
       continue;
     }
-    const size_t k = group_.size();
-    std::vector<int> rcs(k, EPV_OK);
-    std::vector<uint64_t> acc(k, 0);
+    const size_t P = parts_.size();
+    std::vector<int> rcs(P, EPV_OK);
+    std::vector<uint64_t> acc(P, 0);
     std::vector<std::thread> th;
-    for (size_t j = 0; j < k; ++j)
-      th.emplace_back([&, j] { rcs[j] = epv_sweep(group_[j], kk, seed, sweep_base + (uint32_t)done, &acc[j]); });
+    for (size_t p = 0; p < P; ++p)
+      th.emplace_back([&, p] { rcs[p] = epv_sweep(parts_[p].ctx, kk, seed, sweep_base + (uint32_t)done, &acc[p]); });
     for (std::thread &t : th) t.join();
-    for (size_t j = 0; j < k; ++j) { check_on(group_[j], rcs[j], "epv_sweep"); n_acc += acc[j]; }
+    bool grew = false;
+    for (size_t p = 0; p < P; ++p) {
+      epv_ctx *c = parts_[p].ctx;
+      if (rcs[p] == EPV_ERR_CAPACITY) {
+        uint32_t cap = 0;
+        if (epv_get_capacity(c, &cap) == EPV_OK && cap < kMaxCap) {
+          capacity_events.push_back(std::string("epv_sweep: ") + epv_last_error(c));
+          check_on(c, epv_set_capacity(c, std::min(kMaxCap, cap * 2u)), "epv_set_capacity");
+          rcs[p] = EPV_OK;
+          grew = true;
+        }
+      }
+      check_on(c, rcs[p], "epv_sweep");
+      n_acc += acc[p];
+    }
+    // the parts update their shared halo columns redundantly: they must keep proposing under
+    // the same capacity, or one accepts what the other rejects
+    if (grew) equalize_capacity();
     done += kk;
   }
   return n_acc;
 }
 
 void SingleSiteSampler::scale_jump_times(const std::vector<double> &new_branches) {
-  for (epv_ctx *c : group_) check_on(c, epv_scale_jump_times(c, new_branches.data()), "epv_scale_jump_times");
+  if (!sharded()) { check(epv_scale_jump_times(ctx_, new_branches.data()), "epv_scale_jump_times"); return; }
+  for (Part &p : parts_) check_on(p.ctx, epv_scale_jump_times(p.ctx, new_branches.data()), "epv_scale_jump_times");
 }
 
 void SingleSiteSampler::upload(const Tree &th, const FlatPaths &paths) {
-  drop_group();   // the site-independent stage runs on one context
+  drop_parts();   // the site-independent stage runs on one context
   n_nodes_ = th.n_nodes();
   n_sites_ = paths.n_sites;
   check(epv_set_tree(ctx_, th.n_nodes(), th.parent_ids.data(), th.subtree_sizes.data(),
@@ -287,7 +518,7 @@ void SingleSiteSampler::upload(const Tree &th, const FlatPaths &paths) {
 
 void SingleSiteSampler::get_sufficient_statistics(std::vector<std::vector<double>> &J,
                                                   std::vector<std::vector<double>> &D) {
-  if (grouped()) throw std::runtime_error("get_sufficient_statistics: load the paths with upload() (one context)");
+  if (sharded()) throw std::runtime_error("get_sufficient_statistics: load the paths with upload() (one context)");
   const size_t B = (size_t)n_nodes_ - 1;
   std::vector<double> Jf(B * 8), Df(B * 8);
   check(epv_get_sufficient_statistics(ctx_, Jf.data(), Df.data()), "epv_get_sufficient_statistics");
@@ -317,14 +548,14 @@ void SingleSiteSampler::indep_update_paths(const double rates[2], uint64_t seed,
 }
 
 void SingleSiteSampler::download(FlatPaths &paths) {
-  if (grouped()) {
+  if (sharded()) {
     std::vector<FlatPaths> owned;
-    for (size_t j = 0; j < group_.size(); ++j) {
-      epv_ctx *c = group_[j];
+    for (Part &q : parts_) {
+      epv_ctx *c = q.ctx;
       uint64_t total = 0;
       check_on(c, epv_paths_total_jumps(c, &total), "epv_paths_total_jumps");
       FlatPaths p;
-      p.n_sites = hi_[j] - lo_[j];
+      p.n_sites = q.hi - q.lo;
       p.n_nodes = n_nodes_;
       const uint64_t E = (uint64_t)(n_nodes_ - 1) * p.n_sites;
       p.init.assign(E, 0);
@@ -332,7 +563,7 @@ void SingleSiteSampler::download(FlatPaths &paths) {
       p.jumps.assign(total ? total : 1, 0.0);
       check_on(c, epv_download_paths(c, p.init.data(), p.offsets.data(), p.jumps.data()), "epv_download_paths");
       p.jumps.resize(total);
-      owned.push_back(slice_sites(p, a_[j] - lo_[j], b_[j] - lo_[j]));
+      owned.push_back(slice_sites(p, q.a - q.lo, q.b - q.lo));
     }
     paths = concat_sites(owned);
     return;

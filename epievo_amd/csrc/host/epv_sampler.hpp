@@ -1,21 +1,30 @@
 // epv_sampler.hpp -- host-side C++ face of the GPU sampler, shaped like the reference's
 // SingleSiteSampler (/root/reference/src/libepievo/SingleSiteSampler.hpp:35-81) so that
 // the EM driver reads like the reference's (epievo_est_params_histories.cpp:236-264).
-// It is a thin wrapper over the C ABI of include/epievo_mi355x.h; errors become
-// std::runtime_error (the reference's mains catch std::exception and return
-// EXIT_FAILURE, epievo_est_params_histories.cpp:296-299).
+// It is a wrapper over the C ABIs of include/epievo_mi355x.h (kernels) and
+// include/epievo_mi355x_comm.h (RCCL); errors become std::runtime_error (the reference's mains
+// catch std::exception and return EXIT_FAILURE, epievo_est_params_histories.cpp:296-299).
 //
 // Differences forced by the device boundary:
 //  * paths live on the GPU between calls: reset(model, tree, paths) uploads them once,
 //    reset(model) re-derives the cached log-likelihoods after a model change, and
 //    download(paths) brings them back when the driver wants to write them;
 //  * the reference threads one std::mt19937 through every call; the parallel schedule
-//    uses a counter-based stream, so run_mcmc takes (seed, em_iteration) instead;
-//  * the EM driver's path (reset / run_mcmc / scale_jump_times / download) runs TWO contexts
-//    per GPU when the genome is long enough (EPV_CONTEXTS_PER_GPU, default 2): each owns a
-//    range of whole 256-site blocks plus 512 redundant halo columns, their dependent kernels
-//    overlap on two streams, and the statistics come from shared block partials, so every
-//    result is bit-identical to one context.
+//    uses a counter-based stream, so run_mcmc takes (seed, em_iteration) instead.
+//
+// Sharding (new; the reference is single-threaded).  The genome is cut into PARTS in genome
+// order: G device slots (one per GPU of the node: EPV_DEVICES / the constructor's device list)
+// times k contexts per GPU (EPV_CONTEXTS_PER_GPU, default 2).  Every part owns whole 256-site
+// blocks plus redundant halo columns wide enough for a whole run_mcmc; the RNG and the colouring
+// are keyed by the global site index, so the parts need no communication inside the E-step.
+// Per EM iteration the slots exchange, device to device through RCCL,
+//   (1) the edge columns of neighbouring parts before reset()   (epv_comm_exchange), and
+//   (2) their rows of the J/D reduction tree after run_mcmc()   (epv_comm_all_gather);
+// slots are cut on whole rows, every stage sums aligned subtrees of ONE balanced binary tree
+// over the site index, and so paths, J, D and the acceptance rate are bit-identical to the
+// one-context run for any G and k.  A device list with repeats
+// (EPV_DEVICES=0,0,0,0) rehearses an N-GPU run on a smaller box through the loopback transport
+// of the exchange layer.
 #ifndef EPV_SAMPLER_HPP
 #define EPV_SAMPLER_HPP
 
@@ -28,12 +37,19 @@
 #include "epv_model.hpp"
 
 struct epv_ctx;
+struct epv_comm;
 
 namespace epv {
+
+// "all" | "0,1,2,3" | "" (-> {0}); repeats allowed (rehearsal).  Throws on a malformed list.
+std::vector<int> parse_device_list(const std::string &spec);
+// the device list of the environment (EPV_DEVICES), {0} when unset
+std::vector<int> devices_from_env();
 
 class SingleSiteSampler {
 public:
   SingleSiteSampler(size_t n_burn_in, size_t n_batch, int device = 0, uint32_t capacity = 0);
+  SingleSiteSampler(size_t n_burn_in, size_t n_batch, const std::vector<int> &devices, uint32_t capacity = 0);
   ~SingleSiteSampler();
   SingleSiteSampler(const SingleSiteSampler &) = delete;
   SingleSiteSampler &operator=(const SingleSiteSampler &) = delete;
@@ -79,20 +95,49 @@ public:
   // capacity overflows that were absorbed by widening the device jump slots (verbose output)
   std::vector<std::string> capacity_events;
 
+  // how the genome is laid out right now (verbose output, tests)
+  size_t n_parts() const { return parts_.size(); }
+  size_t n_slots() const { return slots_.size(); }
+  bool uses_rccl() const;
+  std::string layout() const;
+
 private:
+  struct Part {            // one context: local columns [lo, hi), owned columns [a, b) of the genome
+    epv_ctx *ctx = nullptr;
+    size_t slot = 0;
+    uint64_t lo = 0, a = 0, b = 0, hi = 0;
+  };
+  struct Slot {            // one GPU of the run (or one rehearsal slot on a shared GPU)
+    int device = 0;
+    epv_comm *comm = nullptr;
+    uint64_t first = 0, last = 0;        // owned columns [first, last) of the genome
+    size_t part0 = 0, part1 = 0;         // its parts [part0, part1)
+    uint64_t n_blocks = 0, n_rows = 0;
+    void *d_blocks = nullptr;            // [batch][n_blocks][V] level-0 partials of the slot
+    void *d_rows = nullptr;              // [max_rows][batch][V] rows of the slot (zero padded)
+    void *d_gather = nullptr;            // [slots][max_rows][batch][V]
+    void *d_halo[4] = {nullptr, nullptr, nullptr, nullptr};  // send prev, recv prev, send next, recv next
+    uint64_t halo_bytes = 0;
+  };
   void check(int rc, const char *what);
   void check_mcmc(int rc, const char *what);
   void check_on(epv_ctx *c, int rc, const char *what);
-  bool grouped() const { return group_.size() > 1; }
-  void drop_group();          // back to the single context ctx_
-  void refresh_group();       // equal capacities, internal halo columns, fresh halo marks
-  epv_ctx *ctx_;
-  int device_;
+  void check_comm(epv_comm *c, int rc, const char *what);
+  bool sharded() const { return !parts_.empty(); }
+  void drop_parts();          // back to the single context ctx_
+  void refresh_parts();       // equal capacities, halo columns of every inner edge, fresh halo marks
+  void equalize_capacity();
+  void ensure_stat_buffers();
+  void free_stat_buffers();
+  epv_ctx *ctx_;              // the context of the unsharded paths (== parts_[0].ctx when sharded)
+  std::vector<int> devices_;
   int contexts_wanted_ = 2;
-  std::vector<epv_ctx *> group_;            // group_[0] == ctx_ when several contexts share the GPU
-  std::vector<uint64_t> lo_, a_, b_, hi_;   // local range [lo, hi) and owned range [a, b) of each
-  void *d_blocks_ = nullptr;                // [batch][blocks][16 (N-1)] level-0 partials of the group
-  uint64_t blocks_batch_ = 0;
+  uint32_t row_blocks_ = 64;  // 256-site blocks per row of the cross-GPU statistics stage
+  bool force_comm_ = false;   // EPV_FORCE_COMM=1: the exchange layer even for one slot (tests)
+  std::vector<Part> parts_;
+  std::vector<Slot> slots_;
+  uint64_t halo_ = 0;         // halo columns at every inner edge (multiple of 256)
+  uint64_t max_rows_ = 0, stat_batch_ = 0;
   uint32_t capacity_;
   int n_nodes_ = 0;
   uint64_t n_sites_ = 0;

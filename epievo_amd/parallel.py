@@ -1,6 +1,10 @@
-"""Site-sharded multi-GPU driver: one process per GPU, contiguous shards of the genome
-with WIDE halos that are updated redundantly, refreshed once per run_mcmc, and one
-exchange of the per-branch J/D (+ accept count) per run_mcmc.
+"""Site-sharded multi-GPU driver for launchers that start ONE PROCESS PER GPU (torchrun:
+bench.py, the multi-process tests); the C++ EM driver shards inside one process instead
+(epievo_amd/csrc/host/epv_sampler.cpp, RCCL linked directly).  Both stand on the same C-ABI
+primitives and the same layout rules.
+
+Contiguous shards of the genome with WIDE halos that are updated redundantly, refreshed once
+per run_mcmc, and ONE all-gather of the per-branch J/D rows (+ accept count) per run_mcmc.
 
 Why it is correct: one MH update of site i reads the paths of sites
 i-2..i+2 and the cached triple log-likelihoods tri[i-1], tri[i+1]; it writes path i and
@@ -8,13 +12,17 @@ tri[i-1..i+1].  The RNG and the 3-colouring are keyed by the GLOBAL site index, 
 rank that holds copies of a neighbour's edge columns can update them itself and obtain
 exactly what the owner computes.  Each colour phase, the two outermost still-valid halo
 columns at every shard-internal edge lose a neighbour and go stale, so a halo of H
-columns lasts H/2 phases = H/6 sweeps.  With H = 6*(burn_in + batch) + 2 a whole
+columns lasts H/2 phases = H/6 sweeps.  With H >= 6*(burn_in + batch) + 2 a whole
 run_mcmc needs NO communication inside it: the halos are refreshed once before
-reset(), and J/D/accepts are combined once after it -- instead of 3 exchanges per
-sweep.  The redundant work is 2H/n of a shard (0.07 % at n = 1e6, -L 10 -B 50).
-A sharded run reproduces the unsharded one bit-for-bit on paths, states and J; D
-differs only in summation order across shards (per-shard canonical trees added in
-rank order).
+reset(), and the statistics are combined once after it -- instead of 3 exchanges per
+sweep.  The redundant work is 2H/n of a shard (0.1 % at n = 1e6, -L 10 -B 50).
+
+Statistics.  Shards are cut on multiples of ROW = 256 * row_blocks sites.  Every rank reduces
+its 256-site block partials to rows of ROW sites on its GPU, the rows of all ranks are
+all-gathered (device buffers handed to RCCL as they are), and every rank sums all rows of
+the genome.  Each stage adds aligned subtrees of ONE balanced binary tree over the global
+site index, so a sharded run reproduces the unsharded one bit-for-bit on paths, states, J
+AND D, for any number of ranks.
 
 The reference has no parallelism at all (single-threaded); this
 module is new capability, not a translation.
@@ -23,7 +31,22 @@ import numpy as np
 
 from .host import FlatPaths
 
-HALO = 2
+BLOCK = 256      # sites per level-0 block of the statistics tree
+TAIL = 8         # doubles appended to a rank's rows in the all-gather (accept count)
+
+
+def halo_width(sweeps_per_refresh):
+    """halo columns that last `sweeps_per_refresh` sweeps, in whole 256-site blocks"""
+    return max(BLOCK, -(-(6 * int(sweeps_per_refresh) + 2) // BLOCK) * BLOCK)
+
+
+def shard_cuts(n_global, world, row_blocks=64):
+    """cut points of `world` near-equal contiguous shards on whole statistics rows"""
+    row = BLOCK * row_blocks
+    cuts = [0] + [int(r * n_global / float(world) / row + 0.5) * row for r in range(1, world)] + [n_global]
+    if any(b <= a for a, b in zip(cuts[:-1], cuts[1:])):
+        raise ValueError("a genome of %d sites is too short for %d shards on %d-site rows" % (n_global, world, row))
+    return cuts
 
 
 def concat_sites(parts):
@@ -45,57 +68,82 @@ def concat_sites(parts):
 
 
 class NullComm:
+    """one rank: nothing to exchange, the gathered buffer IS the rank's piece"""
     rank, world = 0, 1
 
-    def exchange(self, to_left, to_right):
-        return None, None
+    def exchange(self, dev, send_left, recv_left, send_right, recv_right):
+        pass
 
-    def allgather(self, arr):
-        return [np.asarray(arr)]
+    def all_gather(self, dev, piece, gathered):
+        assert gathered is piece
 
 
 class TorchComm:
-    """torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
-    CPU tests).  Messages are tiny (two packed columns; (n_nodes-1)*16 doubles), so the
-    cost is latency only; they go through device tensors when the backend needs it."""
+    """torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
+    tests).  The buffers are the device's own (DevBuf: device memory seen by torch through the
+    CUDA array interface; the CPU double hands out numpy arrays), so nothing is staged: RCCL
+    reads the packed columns and the statistic rows where the kernels wrote them."""
 
     def __init__(self, dist, device=None):
         import torch
         self.dist, self.torch = dist, torch
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device if device is not None else torch.device("cpu")
+        # gloo cannot move GPU tensors: when several ranks SHARE one GPU to rehearse the N > 1
+        # path on a 1-GPU box, device buffers are bounced through the host here (rehearsal only;
+        # with the nccl backend RCCL reads and writes the device buffers directly)
+        self.staged = self.device.type == "cuda" and dist.get_backend() == "gloo"
 
-    def _t(self, a):
-        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+    def _t(self, buf):
+        if hasattr(buf, "np"):                       # host buffer of the CPU device double
+            return self.torch.from_numpy(buf.np)
+        return self.torch.as_tensor(buf, device=self.device)   # zero-copy view of device memory
 
-    def exchange(self, to_left, to_right):
-        """send byte arrays to the left/right neighbour, receive theirs (same sizes)"""
-        dist, torch = self.dist, self.torch
-        ops, rl, rr = [], None, None
-        if self.rank > 0:
-            rl = torch.empty(len(to_left), dtype=torch.uint8, device=self.device)
-            ops.append(dist.P2POp(dist.isend, self._t(to_left), self.rank - 1))
-            ops.append(dist.P2POp(dist.irecv, rl, self.rank - 1))
-        if self.rank < self.world - 1:
-            rr = torch.empty(len(to_right), dtype=torch.uint8, device=self.device)
-            ops.append(dist.P2POp(dist.isend, self._t(to_right), self.rank + 1))
-            ops.append(dist.P2POp(dist.irecv, rr, self.rank + 1))
+    def _sync(self):
+        if self.device.type == "cuda":
+            self.torch.cuda.synchronize(self.device)
+
+    def exchange(self, dev, send_left, recv_left, send_right, recv_right):
+        """swap halo buffers with the left/right neighbour (None = no neighbour on that side)"""
+        dist = self.dist
+        ops, back = [], []
+
+        def add(send, recv, peer):
+            ts, tr = self._t(send), self._t(recv)
+            if self.staged:
+                ts, dst = ts.cpu(), tr
+                tr = self.torch.empty(tr.shape, dtype=tr.dtype)
+                back.append((dst, tr))
+            ops.append(dist.P2POp(dist.isend, ts, peer))
+            ops.append(dist.P2POp(dist.irecv, tr, peer))
+
+        if send_left is not None:
+            add(send_left, recv_left, self.rank - 1)
+        if send_right is not None:
+            add(send_right, recv_right, self.rank + 1)
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        return (rl.cpu().numpy() if rl is not None else None,
-                rr.cpu().numpy() if rr is not None else None)
+        for dst, tmp in back:
+            dst.copy_(tmp)
+        self._sync()
 
-    def allgather(self, arr):
-        t = self._t(np.asarray(arr))
-        outs = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t)
-        return [o.cpu().numpy() for o in outs]
+    def all_gather(self, dev, piece, gathered):
+        g, p = self._t(gathered), self._t(piece)
+        if self.staged:
+            outs = [self.torch.empty(p.shape, dtype=p.dtype) for _ in range(self.world)]
+            self.dist.all_gather(outs, p.cpu())
+            g.copy_(self.torch.cat(outs))
+        elif self.device.type == "cuda":
+            self.dist.all_gather_into_tensor(g, p)         # one RCCL all-gather, in place
+        else:
+            self.dist.all_gather(list(g.chunk(self.world)), p)
+        self._sync()
 
 
 class ShardedSampler:
     """SingleSiteSampler over a site-sharded genome.  `device_factory(device)` builds the
-    per-rank engine (the HIP DeviceSampler in the product; the tests inject an
+    per-rank engine (the HIP DeviceSampler / LocalGroup in the product; the tests inject an
     oracle-backed double to check the sharding logic on CPU with gloo)."""
 
     def __init__(self, comm, device=0, device_factory=None):
@@ -110,20 +158,33 @@ class ShardedSampler:
         if hasattr(self.dev, "auto_grow"):
             self.dev.auto_grow = True
         self.halo = 0
+        self._halo_bufs, self._halo_bytes = None, 0
+        self._piece = self._gathered = None
+        self._piece_batch = 0
 
     def owned_sites(self):
         return self.n_own - (1 if self.comm.rank == 0 else 0) - \
             (1 if self.comm.rank == self.comm.world - 1 else 0)
 
-    def setup(self, model, tree, fp_own, n_global, capacity=16, sweeps_per_refresh=60):
-        """fp_own: this rank's owned columns (every rank owns the same number of sites).
-        The halo is sized for `sweeps_per_refresh` sweeps between refreshes."""
+    def setup(self, model, tree, fp_own, cuts, capacity=16, sweeps_per_refresh=60, row_blocks=64):
+        """fp_own: this rank's owned columns, sites [cuts[rank], cuts[rank+1]) of the genome
+        (cuts from shard_cuts: whole statistics rows).  The halo is sized for
+        `sweeps_per_refresh` sweeps between refreshes."""
         c = self.comm
-        n_own = fp_own.n_sites
+        cuts = [int(x) for x in cuts]
+        if len(cuts) != c.world + 1 or cuts[0] != 0:
+            raise ValueError("cuts must list world + 1 cut points starting at 0")
+        row = BLOCK * row_blocks
+        if any(x % row for x in cuts[1:-1]):
+            raise ValueError("inner cut points must be multiples of %d sites" % row)
+        n_own, n_global = cuts[c.rank + 1] - cuts[c.rank], cuts[-1]
+        if fp_own.n_sites != n_own:
+            raise ValueError("fp_own has %d sites, the cuts give this rank %d" % (fp_own.n_sites, n_own))
+        self.cuts, self.row_blocks = cuts, row_blocks
         self.n_own, self.n_global, self.B = n_own, n_global, tree.n_nodes - 1
-        H = 6 * sweeps_per_refresh + 2 if c.world > 1 else 0
-        if H > n_own:
-            raise ValueError("shards of %d sites are too small for a %d-column halo" % (n_own, H))
+        H = halo_width(sweeps_per_refresh) if c.world > 1 else 0
+        if H > min(b - a for a, b in zip(cuts[:-1], cuts[1:])):
+            raise ValueError("a shard is smaller than the %d-column halo" % H)
         self.halo = H
         left = H if c.rank > 0 else 0
         right = H if c.rank < c.world - 1 else 0
@@ -136,30 +197,51 @@ class ShardedSampler:
         fp_loc = concat_sites(parts) if len(parts) > 1 else fp_own
         self.n_loc = fp_loc.n_sites
         self.left, self.right = left, right
-        self.g0 = c.rank * n_own - left
+        self.g0 = cuts[c.rank] - left
+        # statistics rows of every rank (all ranks compute the same table)
+        self.rows_per_rank = [(-(-(b - a) // BLOCK) + row_blocks - 1) // row_blocks for a, b in zip(cuts[:-1], cuts[1:])]
+        self.max_rows = max(self.rows_per_rank)
         self.dev.set_tree(tree)
         self.dev.set_model(model)
         self.dev.upload_paths(fp_loc, capacity, self.g0, n_global)
         self.dev.set_halo(left, right)
         self.refresh_halos()
 
+    def _agree_on_capacity(self):
+        """packed columns have capacity-dependent size: all ranks move to the widest"""
+        if self.comm.world == 1 or not hasattr(self.dev, "capacity"):
+            return
+        piece, gathered = self.dev.alloc(8), self.dev.alloc(8 * self.comm.world)
+        self.dev.write(piece, 0, np.array([float(self.dev.capacity())]))
+        self.comm.all_gather(self.dev, piece, gathered)
+        cap = int(self.dev.read(gathered, 0, self.comm.world).max())
+        piece.free()
+        gathered.free()
+        if cap != self.dev.capacity():
+            self.dev.set_capacity(cap)
+
     def refresh_halos(self):
         """ship my H outermost owned columns to each neighbour; take theirs as my halos"""
         if self.comm.world == 1:
             return
-        if hasattr(self.dev, "capacity"):
-            # packed columns have capacity-dependent size: agree on the widest
-            caps = [int(x[0]) for x in self.comm.allgather(np.array([float(self.dev.capacity())]))]
-            if max(caps) != self.dev.capacity():
-                self.dev.set_capacity(max(caps))
+        self._agree_on_capacity()
         H = self.halo
-        to_left = self.dev.get_columns(self.left, H) if self.left else None
-        to_right = self.dev.get_columns(self.n_loc - self.right - H, H) if self.right else None
-        from_left, from_right = self.comm.exchange(to_left, to_right)
-        if from_left is not None:
-            self.dev.put_columns(0, H, from_left)
-        if from_right is not None:
-            self.dev.put_columns(self.n_loc - H, H, from_right)
+        nbytes = H * self.dev.column_bytes()
+        if self._halo_bufs is None or self._halo_bytes != nbytes:
+            for b in self._halo_bufs or []:
+                b.free()
+            self._halo_bufs, self._halo_bytes = [self.dev.alloc(nbytes) for _ in range(4)], nbytes
+        sl, rl, sr, rr = self._halo_bufs
+        if self.left:
+            self.dev.pack_columns(self.left, H, sl)
+        if self.right:
+            self.dev.pack_columns(self.n_loc - self.right - H, H, sr)
+        self.comm.exchange(self.dev, sl if self.left else None, rl if self.left else None,
+                           sr if self.right else None, rr if self.right else None)
+        if self.left:
+            self.dev.unpack_columns(0, H, rl)
+        if self.right:
+            self.dev.unpack_columns(self.n_loc - H, H, rr)
         self.dev.set_halo(self.left, self.right)     # marks the halos fresh
 
     # ---- SingleSiteSampler interface
@@ -187,23 +269,29 @@ class ShardedSampler:
         return nacc
 
     def run_mcmc(self, burn_in, batch, seed, sweep_base=0):
-        """-> (J, D, acc_rate): batch averages over the WHOLE genome, identical on every rank"""
+        """-> (J, D, acc_rate): batch averages over the WHOLE genome, identical on every rank
+        and bit-identical to the unsharded run"""
         if self.comm.world > 1 and self.dev.halo_phases_left() < 3 * (burn_in + batch):
             raise RuntimeError("halo too narrow for %d sweeps: call reset() first or set up with "
                                "a larger sweeps_per_refresh" % (burn_in + batch))
-        if self.comm.world == 1:
-            J, D, nacc = self.dev.run_mcmc(burn_in, batch, seed, sweep_base)
-        else:
-            # shards return batch SUMS; the one exchange per EM iteration adds them in rank
-            # order ([J | D | n_acc]; J and n_acc are integers, hence exact) and the division
-            # by the batch size happens once, as in the unsharded run
-            J, D, nacc = self.dev.run_mcmc(burn_in, batch, seed, sweep_base, average=False)
-            parts = self.comm.allgather(np.concatenate([J, D, [float(nacc)]]))
-            tot = np.zeros_like(parts[0])
-            for p in parts:
-                tot = tot + p
-            J, D, nacc = (tot[:self.B * 8] / float(batch), tot[self.B * 8:self.B * 16] / float(batch),
-                          tot[-1])
+        V = self.B * 16
+        piece_doubles = self.max_rows * batch * V + TAIL
+        if self._piece is None or self._piece_batch != batch:
+            for b in {id(x): x for x in (self._piece, self._gathered) if x is not None}.values():
+                b.free()
+            self._piece = self.dev.alloc(piece_doubles * 8)
+            self._gathered = self.dev.alloc(piece_doubles * 8 * self.comm.world) if self.comm.world > 1 \
+                else self._piece
+            self._piece_batch = batch
+        # this rank's rows of the statistics tree stay on the device; the accept count rides in
+        # the tail of the same piece, so ONE collective per EM iteration carries everything
+        nacc = self.dev.run_mcmc_rows(burn_in, batch, seed, sweep_base, self.row_blocks, self._piece)
+        self.dev.write(self._piece, (piece_doubles - TAIL) * 8, np.array([float(nacc)]))
+        self.comm.all_gather(self.dev, self._piece, self._gathered)
+        J, D = self.dev.reduce_gathered_rows(self._gathered, self.max_rows, piece_doubles, self.rows_per_rank,
+                                             batch, True)
+        nacc = sum(float(self.dev.read(self._gathered, ((r + 1) * piece_doubles - TAIL) * 8, 1)[0])
+                   for r in range(self.comm.world))
         return J, D, nacc / float(batch * (self.n_global - 2))
 
     def scale_jump_times(self, new_branches):
@@ -227,19 +315,19 @@ class LocalGroup:
     (epv_run_mcmc_blocks / epv_reduce_blocks).  Drop-in for DeviceSampler inside
     ShardedSampler, so it composes with the multi-GPU sharding."""
 
-    H_INT = 512        # internal halo columns: >= 6 * 60 + 2 and a multiple of 256
     BLOCK = 256
 
-    def __init__(self, device=0, shards=2):
+    def __init__(self, device=0, shards=2, sweeps_per_refresh=60):
         from concurrent.futures import ThreadPoolExecutor
         from .sampler import DeviceSampler
         self.device, self.k_req = device, max(1, int(shards))
+        self.H_INT = halo_width(sweeps_per_refresh)   # internal halo columns (whole blocks)
         self.subs = [DeviceSampler(device) for _ in range(self.k_req)]
         self.pool = ThreadPoolExecutor(max_workers=self.k_req)
         self.n_sites = self.n_nodes = self.B = 0
         self.capacity_events = []
         self._auto_grow = False
-        self._blocks, self._blocks_batch = None, 0
+        self._blocks, self._blocks_shape = None, None
         self.outer = (0, 0)
         self.halo_mode = False
 
@@ -260,7 +348,7 @@ class LocalGroup:
         self._closed = True
         try:
             if self._blocks is not None and self.subs and self.subs[0].h:
-                self.subs[0].dev_free(self._blocks)
+                self._blocks.free()
         finally:
             self._blocks = None
             for s in self.subs:
@@ -313,8 +401,8 @@ class LocalGroup:
 
     def _drop_blocks(self):
         if self._blocks is not None:
-            self.subs[0].dev_free(self._blocks)
-        self._blocks, self._blocks_batch = None, 0
+            self._blocks.free()
+        self._blocks, self._blocks_shape = None, None
 
     # ---- halos
     def set_halo(self, left, right):
@@ -339,6 +427,24 @@ class LocalGroup:
 
     def column_bytes(self):
         return self.subs[0].column_bytes()
+
+    # buffers live on the group's GPU; any context can allocate and fill them
+    def alloc(self, nbytes):
+        return self.subs[0].alloc(nbytes)
+
+    def write(self, buf, offset, arr):
+        self.subs[0].write(buf, offset, arr)
+
+    def read(self, buf, offset, count, dtype=np.float64):
+        return self.subs[0].read(buf, offset, count, dtype)
+
+    def pack_columns(self, first, count, buf):
+        j, f = self._locate(first, count)
+        self.subs[j].pack_columns(f, count, buf)
+
+    def unpack_columns(self, first, count, buf):
+        j, f = self._locate(first, count)
+        self.subs[j].unpack_columns(f, count, buf)
 
     def get_columns(self, first, count):
         j, f = self._locate(first, count)
@@ -366,6 +472,17 @@ class LocalGroup:
         self._refresh_internal()
         self._each(lambda j, s: s.reset())
 
+    def _sweep_all(self, k, seed, sweep_base):
+        nacc = sum(self._each(lambda j, s: s.sweep(k, seed, sweep_base)))
+        # the shards update their shared halo columns redundantly: after an absorbed overflow
+        # they must go on proposing under ONE capacity, or one accepts what the other rejects
+        if len(self.subs) > 1 and len({s.capacity() for s in self.subs}) > 1:
+            self.set_capacity(max(s.capacity() for s in self.subs))
+        for s in self.subs:
+            self.capacity_events += s.capacity_events
+            s.capacity_events = []
+        return nacc
+
     def sweep(self, n_sweeps, seed, sweep_base=0):
         if len(self.subs) > 1 and self.halo_phases_left() < 3 * n_sweeps:
             done = 0
@@ -375,30 +492,52 @@ class LocalGroup:
                 if kk == 0:
                     self.reset()
                     continue
-                nacc += sum(self._each(lambda j, s: s.sweep(kk, seed, sweep_base + done)))
+                nacc += self._sweep_all(kk, seed, sweep_base + done)
                 done += kk
             return nacc
-        return sum(self._each(lambda j, s: s.sweep(n_sweeps, seed, sweep_base)))
+        return self._sweep_all(n_sweeps, seed, sweep_base)
 
-    def run_mcmc(self, burn_in, batch, seed, sweep_base=0, average=True):
-        if len(self.subs) == 1:
-            return self.subs[0].run_mcmc(burn_in, batch, seed, sweep_base, average)
-        if self.halo_phases_left() < 3 * (burn_in + batch):
+    def owned_blocks(self):
+        """(first local 256-site block with owned columns, number of such blocks)"""
+        left, right = self.outer
+        b0 = left // self.BLOCK
+        return b0, (self.n_sites - right + self.BLOCK - 1) // self.BLOCK - b0
+
+    def _run_blocks(self, burn_in, batch, seed, sweep_base):
+        """all shards' run_mcmc with the level-0 partials of the group's owned blocks in ONE
+        device buffer [batch][n_blocks][16 B] -> (accepted, n_blocks)"""
+        if self.halo_phases_left() < 3 * (burn_in + batch) and len(self.subs) > 1:
             raise RuntimeError("internal halo of %d columns is too narrow for %d sweeps without a "
                                "reset()" % (self.H_INT, burn_in + batch))
-        nb_total = (self.n_sites + self.BLOCK - 1) // self.BLOCK
-        V = self.B * 16
-        if self._blocks is None or self._blocks_batch < batch:
+        if self.outer[0] % self.BLOCK:
+            raise ValueError("the group's left halo must be a whole number of 256-site blocks")
+        b0, nb = self.owned_blocks()
+        shape = (batch, nb, self.B)
+        if self._blocks is None or self._blocks_shape != shape:
             self._drop_blocks()
-            self._blocks = self.subs[0].dev_alloc(batch * nb_total * V * 8)
-            self._blocks_batch = batch
-        nacc = sum(self._each(lambda j, s: s.run_mcmc_blocks(burn_in, batch, seed, sweep_base, self._blocks,
-                                                             nb_total, self.lo[j] // self.BLOCK)))
+            self._blocks, self._blocks_shape = self.subs[0].alloc(batch * nb * self.B * 16 * 8), shape
+        nacc = sum(self._each(lambda j, s: s.run_mcmc_blocks(burn_in, batch, seed, sweep_base, self._blocks.p,
+                                                             nb, self.lo[j] // self.BLOCK - b0)))
         for s in self.subs:
             self.capacity_events += s.capacity_events
             s.capacity_events = []
-        J, D = self.subs[0].reduce_blocks(self._blocks, nb_total, batch, average)
+        return nacc, nb
+
+    def run_mcmc(self, burn_in, batch, seed, sweep_base=0, average=True):
+        if len(self.subs) == 1 and not self.halo_mode:
+            return self.subs[0].run_mcmc(burn_in, batch, seed, sweep_base, average)
+        nacc, nb = self._run_blocks(burn_in, batch, seed, sweep_base)
+        J, D = self.subs[0].reduce_blocks(self._blocks.p, nb, batch, average)
         return J, D, nacc
+
+    def run_mcmc_rows(self, burn_in, batch, seed, sweep_base, row_blocks, rows_buf):
+        """as DeviceSampler.run_mcmc_rows, the group's shards writing one block buffer"""
+        nacc, nb = self._run_blocks(burn_in, batch, seed, sweep_base)
+        self.subs[0].blocks_to_rows(self._blocks.p, nb, batch, row_blocks, rows_buf.ptr)
+        return nacc
+
+    def reduce_gathered_rows(self, gathered_buf, max_rows, piece_doubles, rows_per_rank, batch, average=True):
+        return self.subs[0].reduce_gathered_rows(gathered_buf, max_rows, piece_doubles, rows_per_rank, batch, average)
 
     def scale_jump_times(self, new_branches):
         for s in self.subs:

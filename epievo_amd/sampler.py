@@ -42,7 +42,8 @@ ABI_SYMBOLS = [
     "epv_paths_total_jumps", "epv_download_paths", "epv_get_tri_llh", "epv_column_bytes",
     "epv_get_columns", "epv_put_columns", "epv_copy_columns", "epv_dev_alloc", "epv_dev_free",
     "epv_run_mcmc_blocks", "epv_reduce_blocks", "epv_get_counters", "epv_kernel_time_ms",
-    "epv_set_timing",
+    "epv_set_timing", "epv_pack_columns_dev", "epv_unpack_columns_dev", "epv_device_of",
+    "epv_blocks_to_rows", "epv_reduce_rows", "epv_reduce_gathered_rows", "epv_dev_write", "epv_dev_read",
 ]
 
 
@@ -95,8 +96,17 @@ def lib():
         L.epv_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
         L.epv_dev_free.argtypes = [vp, vp]
         L.epv_run_mcmc_blocks.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp, C.c_uint64,
-                                          C.c_uint64, u64p]
+                                          C.c_int64, u64p]
         L.epv_reduce_blocks.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, dp, dp]
+        L.epv_pack_columns_dev.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
+        L.epv_unpack_columns_dev.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
+        L.epv_device_of.argtypes = [vp]
+        L.epv_blocks_to_rows.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, vp]
+        L.epv_reduce_rows.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, dp, dp]
+        L.epv_reduce_gathered_rows.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u64p, C.c_uint64, C.c_int,
+                                               dp, dp]
+        L.epv_dev_write.argtypes = [vp, vp, vp, C.c_uint64]
+        L.epv_dev_read.argtypes = [vp, vp, vp, C.c_uint64]
         L.epv_get_counters.argtypes = [vp, C.POINTER(_Counters)]
         L.epv_kernel_time_ms.argtypes = [vp, dp, u64p]
         L.epv_set_timing.argtypes = [vp, C.c_int]
@@ -106,6 +116,27 @@ def lib():
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+class DevBuf:
+    """Zero-filled device memory on a context's GPU.  torch (and anything else that speaks the
+    CUDA array interface) sees it without a copy, so the halo columns and statistic rows a
+    sharded run hands to RCCL never pass through the host."""
+
+    def __init__(self, dev, nbytes):
+        self.dev, self.nbytes = dev, int(nbytes)
+        self.p = dev.dev_alloc(self.nbytes)
+        self.ptr = int(self.p.value)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2,
+                "strides": None}
+
+    def free(self):
+        if self.p is not None and self.dev.h:
+            self.dev.dev_free(self.p)
+        self.p, self.ptr = None, 0
 
 
 class DeviceSampler:
@@ -120,9 +151,14 @@ class DeviceSampler:
         self.n_sites = self.n_nodes = self.B = 0
         self.auto_grow = False     # True: widen the jump slots after an overflow and carry on
         self.capacity_events = []  # messages of the overflows that were absorbed
+        self.halo = (0, 0)
+        self._blocks, self._blocks_shape = None, None
 
     def close(self):
         if getattr(self, "h", None):
+            if getattr(self, "_blocks", None) is not None:
+                self._blocks.free()
+                self._blocks = None
             self.L.epv_destroy(self.h)
             self.h = None
 
@@ -173,6 +209,7 @@ class DeviceSampler:
                                          capacity, global_site_offset))
         if n_global is not None:
             self._ck(self.L.epv_set_global_length(self.h, n_global))
+        self.halo = (0, 0)
 
     def init_paths_indep(self, root, leaf, seed, capacity=0):
         root = np.ascontiguousarray(root, np.uint8)
@@ -201,6 +238,7 @@ class DeviceSampler:
 
     def set_halo(self, left, right):
         self._ck(self.L.epv_set_halo(self.h, left, right))
+        self.halo = (int(left), int(right))
 
     def halo_phases_left(self):
         v = C.c_uint64(0)
@@ -285,6 +323,65 @@ class DeviceSampler:
         J, D = np.zeros(self.B * 8), np.zeros(self.B * 8)
         self._ck(self.L.epv_reduce_blocks(self.h, d_blocks, n_blocks_total, batch, int(average),
                                           _p(J, C.c_double), _p(D, C.c_double)))
+        return J, D
+
+    # ---- a genome sharded over several GPUs: device-resident halo columns and statistic rows
+    # (buffers: DevBuf, or anything with .ptr = a device address on this context's GPU)
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def pack_columns(self, first, count, buf):
+        self._ck(self.L.epv_pack_columns_dev(self.h, first, count, C.c_void_p(buf.ptr)))
+
+    def unpack_columns(self, first, count, buf):
+        self._ck(self.L.epv_unpack_columns_dev(self.h, first, count, C.c_void_p(buf.ptr)))
+
+    def owned_blocks(self):
+        """(first local 256-site block with owned columns, number of such blocks)"""
+        left, right = self.halo
+        b0 = left // 256
+        return b0, (self.n_sites - right + 255) // 256 - b0
+
+    def run_mcmc_rows(self, burn_in, batch, seed, sweep_base, row_blocks, rows_buf):
+        """run_mcmc whose statistics stay on the device as rows of the reduction tree:
+        rows_buf[row][w][16 B] doubles, row = row_blocks consecutive blocks of the owned
+        columns (the shard starts on a whole row of the genome).  -> accepted proposals"""
+        if self.halo[0] % 256:
+            raise EpvError(EPV_ERR_ARG, "the left halo must be a whole number of 256-site blocks")
+        b0, nb = self.owned_blocks()
+        shape = (batch, nb, self.B)
+        if self._blocks is None or self._blocks_shape != shape:
+            if self._blocks is not None:
+                self._blocks.free()
+            self._blocks, self._blocks_shape = DevBuf(self, batch * nb * self.B * 16 * 8), shape
+        nacc = self.run_mcmc_blocks(burn_in, batch, seed, sweep_base, self._blocks.p, nb, -b0)
+        self.blocks_to_rows(self._blocks.p, nb, batch, row_blocks, rows_buf.ptr)
+        return nacc
+
+    def blocks_to_rows(self, d_blocks, n_blocks_total, batch, row_blocks, d_rows):
+        self._ck(self.L.epv_blocks_to_rows(self.h, d_blocks, n_blocks_total, batch, row_blocks, C.c_void_p(d_rows)))
+
+    def reduce_rows(self, d_rows, n_rows, batch, average=True):
+        J, D = np.zeros(self.B * 8), np.zeros(self.B * 8)
+        self._ck(self.L.epv_reduce_rows(self.h, C.c_void_p(d_rows), n_rows, batch, int(average),
+                                        _p(J, C.c_double), _p(D, C.c_double)))
+        return J, D
+
+    def write(self, buf, offset, arr):
+        a = np.ascontiguousarray(arr)
+        self._ck(self.L.epv_dev_write(self.h, C.c_void_p(buf.ptr + offset), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def read(self, buf, offset, count, dtype=np.float64):
+        out = np.zeros(count, dtype)
+        self._ck(self.L.epv_dev_read(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(buf.ptr + offset), out.nbytes))
+        return out
+
+    def reduce_gathered_rows(self, gathered_buf, max_rows, piece_doubles, rows_per_rank, batch, average=True):
+        J, D = np.zeros(self.B * 8), np.zeros(self.B * 8)
+        rpr = np.ascontiguousarray(rows_per_rank, np.uint64)
+        self._ck(self.L.epv_reduce_gathered_rows(self.h, C.c_void_p(gathered_buf.ptr), len(rpr), max_rows, piece_doubles,
+                                                 _p(rpr, C.c_uint64), batch, int(average),
+                                                 _p(J, C.c_double), _p(D, C.c_double)))
         return J, D
 
     def counters(self):

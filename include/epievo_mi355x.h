@@ -184,6 +184,11 @@ int epv_get_tri_llh(epv_ctx *ctx, double *out);
 uint64_t epv_column_bytes(const epv_ctx *ctx);
 int epv_get_columns(epv_ctx *ctx, uint64_t first, uint64_t count, void *packed);
 int epv_put_columns(epv_ctx *ctx, uint64_t first, uint64_t count, const void *packed);
+/* the same with the packed columns in DEVICE memory of the context's GPU (the buffer a driver
+ * hands to RCCL: include/epievo_mi355x_comm.h, or a torch tensor's storage); synchronous */
+int epv_pack_columns_dev(epv_ctx *ctx, uint64_t first, uint64_t count, void *d_packed);
+int epv_unpack_columns_dev(epv_ctx *ctx, uint64_t first, uint64_t count, const void *d_packed);
+int epv_device_of(const epv_ctx *ctx);
 /* the same between two contexts of ONE GPU (equal tree and capacity), without leaving the device */
 int epv_copy_columns(epv_ctx *src, uint64_t src_first, uint64_t count, epv_ctx *dst, uint64_t dst_first);
 
@@ -194,16 +199,38 @@ int epv_copy_columns(epv_ctx *src, uint64_t src_first, uint64_t count, epv_ctx *
  * unsharded run the statistics are not reduced per shard: every shard writes the level-0
  * partials of its OWNED 256-site blocks, per batch sweep, into one buffer shared by the group
  * (epv_run_mcmc_blocks; d_blocks[w][block][16 (N-1)] doubles, block_offset = index of the
- * shard's local block 0 in the group), and one canonical reduction (epv_reduce_blocks, on any
+ * shard's local block 0 in the group -- negative when a halo precedes the first owned block of
+ * the buffer; the shard's global_site_offset must be a multiple of 256), and one canonical reduction (epv_reduce_blocks, on any
  * context of the group) adds them up exactly as run_mcmc does on one context.
  * epv_dev_alloc returns zero-filled device memory (blocks nobody owns must read as 0). */
 int epv_dev_alloc(epv_ctx *ctx, uint64_t bytes, void **device_ptr);
 int epv_dev_free(epv_ctx *ctx, void *device_ptr);
+int epv_dev_write(epv_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
+int epv_dev_read(epv_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
 int epv_run_mcmc_blocks(epv_ctx *ctx, uint64_t burn_in, uint64_t batch, uint64_t seed, uint32_t sweep_base,
-                        double *d_blocks, uint64_t n_blocks_total, uint64_t block_offset,
+                        double *d_blocks, uint64_t n_blocks_total, int64_t block_offset,
                         uint64_t *n_accepted);
 int epv_reduce_blocks(epv_ctx *ctx, const double *d_blocks, uint64_t n_blocks_total, uint64_t batch,
                       int average, double *J, double *D);
+
+/* ---- statistics of a genome sharded over several GPUs (new).  Shards are cut on multiples of
+ * 256 * row_blocks sites (row_blocks a power of two).  Every GPU reduces the level-0 partials of
+ * ITS blocks (d_blocks as written by epv_run_mcmc_blocks, nb_total blocks) to rows of row_blocks
+ * blocks, d_rows[row][w][16 (N-1)]; the rows of all GPUs, concatenated in genome order (one RCCL
+ * all-gather per EM iteration), go through epv_reduce_rows.  Every stage is a piece of the same
+ * balanced binary tree over the site index, so J AND D equal the one-context results bit for
+ * bit, whatever the number of GPUs. */
+int epv_blocks_to_rows(epv_ctx *ctx, const double *d_blocks, uint64_t n_blocks_total, uint64_t batch,
+                       uint32_t row_blocks, double *d_rows);
+int epv_reduce_rows(epv_ctx *ctx, const double *d_rows, uint64_t n_rows, uint64_t batch, int average,
+                    double *J, double *D);
+/* the same straight on the output of an all-gather of equally sized pieces:
+ * rank r's piece starts at d_gathered + r * piece_doubles (0 = max_rows * batch * 16 (N-1); larger
+ * when the pieces carry a tail, e.g. the shard's accept count) and is laid out
+ * [max_rows][batch][16 (N-1)], of which the first rows_per_rank[r] rows count */
+int epv_reduce_gathered_rows(epv_ctx *ctx, const double *d_gathered, uint32_t world, uint64_t max_rows,
+                             uint64_t piece_doubles, const uint64_t *rows_per_rank, uint64_t batch, int average,
+                             double *J, double *D);
 
 int epv_get_counters(epv_ctx *ctx, epv_counters *out);
 

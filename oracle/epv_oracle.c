@@ -734,6 +734,21 @@ ORC_API void orc_suffstats_range(const orc_state *st, uint64_t first, uint64_t l
   g_first = 0; g_last = (size_t)-1;
 }
 
+/* Rows of the canonical reduction tree, for the tests of the multi-GPU statistics stage: row r
+ * is the balanced pairwise sum over the row_sites (a power of two) local sites starting at
+ * first_site + r * row_sites, restricted to the owned range [own_first, own_last];
+ * out[r][b-1][16] (J then D).  When first_site sits on a multiple of row_sites of the GENOME these
+ * are subtrees of the whole-genome tree of orc_suffstats. */
+ORC_API void orc_suffstats_rows(const orc_state *st, uint64_t first_site, uint64_t row_sites,
+                                uint64_t n_rows, uint64_t own_first, uint64_t own_last, double *out) {
+  const int B = st->n_nodes - 1;
+  g_first = own_first; g_last = own_last;
+  for (uint64_t r = 0; r < n_rows; ++r)
+    for (int b = 1; b <= B; ++b)
+      tree_sum(st, b, first_site + r * row_sites, row_sites, out + (r * (uint64_t)B + (uint64_t)(b - 1)) * 16);
+  g_first = 0; g_last = (size_t)-1;
+}
+
 /* SingleSiteSampler.cpp:550-598.  J/D are batch averages on return. */
 ORC_API void orc_run_mcmc(orc_state *st, uint64_t burn_in, uint64_t batch,
                           uint32_t sweep_base, double *J, double *D,

@@ -1,65 +1,9 @@
-"""Shared helpers for the test-suite (inputs, configurations)."""
+"""Shared helpers for the test-suite (inputs, configurations): the workloads live in the
+package (epievo_amd/workloads.py) so that bench.py does not depend on the test tree."""
 import os
 
-import numpy as np
-
-from epievo_amd import host
+from epievo_amd.workloads import (EXTRA_TREES, TEST_PARAM_TEXT, TREE_NWK_TEXT, _tmp, config,  # noqa: F401
+                                  ref_test_model, simulate, tree_nwk)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
-
-# the reference's test/test.param and test/tree.nwk, restated as data (2 + 1 lines)
-TEST_PARAM_TEXT = "stationary\t0.844912\t0.893359\nbaseline\t-0.8\t-1.8\n"
-TREE_NWK_TEXT = "((C:0.03,D:0.06)E:0.02,F:0.1)G:0.0;\n"
-# further topologies for the parity tests: a star (root with four children), a tree with an
-# internal trifurcation and one long branch, and a 6-leaf caterpillar
-EXTRA_TREES = {
-    "star4": "(A:0.1,B:0.2,C:0.05,D:0.3)R:0.0;\n",
-    "multi": "((A:0.1,B:0.1,C:0.2)X:0.1,(D:0.3,E:0.05)Y:0.2,F:0.8)R:0.0;\n",
-    "cat6": "(((((A:0.05,B:0.07)U:0.04,C:0.1)V:0.03,D:0.15)W:0.06,E:0.2)Z:0.02,F:0.25)R:0.0;\n",
-}
-
-
-def _tmp(name, text):
-    import tempfile
-    d = os.path.join(tempfile.gettempdir(), "epv_tests_%d" % os.getuid())
-    os.makedirs(d, exist_ok=True)
-    p = os.path.join(d, name)
-    # several rank processes of one test write the same file: never expose a truncated one
-    try:
-        if open(p).read() == text:
-            return p
-    except OSError:
-        pass
-    tmp = "%s.%d.tmp" % (p, os.getpid())
-    with open(tmp, "w") as f:
-        f.write(text)
-    os.replace(tmp, p)
-    return p
-
-
-def ref_test_model():
-    return host.Model.read(_tmp("test.param", TEST_PARAM_TEXT), scale=True)
-
-
-def tree_nwk():
-    return host.Tree.read(_tmp("tree.nwk", TREE_NWK_TEXT))
-
-
-def config(name):
-    """(tree, default n) for the named BASELINE configuration"""
-    if name == "tree":
-        return tree_nwk()
-    if name == "pair":
-        return host.Tree.single_branch(1.0)
-    if name == "bal16":
-        return host.Tree.balanced(16, 0.05)
-    if name in EXTRA_TREES:
-        return host.Tree.read(_tmp(name + ".nwk", EXTRA_TREES[name]))
-    raise KeyError(name)
-
-
-def simulate(name, n, seed=42):
-    m = ref_test_model()
-    t = config(name)
-    return m, t, host.simulate(m, t, n, seed)

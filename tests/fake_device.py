@@ -9,6 +9,30 @@ import orc
 from epievo_amd.host import FlatPaths
 
 
+class HostBuf:
+    """what OracleDevice.alloc hands out: host memory (the product's DevBuf is device memory)"""
+
+    def __init__(self, nbytes):
+        self.np = np.zeros(int(nbytes), np.uint8)
+        self.nbytes = int(nbytes)
+
+    def free(self):
+        pass
+
+
+def tree_total(rows):
+    """balanced pairwise sum over axis 0, zero padded to a power of two (numpy restatement of
+    the last stage of the device reduction, epv_rowsum_kernel with G = 0)"""
+    m = rows.shape[0]
+    pad = 1
+    while pad < m:
+        pad *= 2
+    cur = np.concatenate([rows, np.zeros((pad - m,) + rows.shape[1:])], axis=0)
+    while cur.shape[0] > 1:
+        cur = cur[0::2] + cur[1::2]
+    return cur[0]
+
+
 class OracleDevice:
     def __init__(self, device=0):
         self.o = None
@@ -96,11 +120,25 @@ class OracleDevice:
     def paths(self):
         return self.o.paths()
 
+    # ---- device-style buffers
+    def alloc(self, nbytes):
+        return HostBuf(nbytes)
+
+    def write(self, buf, offset, arr):
+        a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        buf.np[offset:offset + a.size] = a
+
+    def read(self, buf, offset, count, dtype=np.float64):
+        return buf.np[offset:offset + count * np.dtype(dtype).itemsize].view(dtype).copy()
+
+    def capacity(self):
+        return self.cap
+
     # ---- columns: [count][B] init u8 | [count][B] cnt u32 | [count][B][cap] f64
     def column_bytes(self):
         return self.B * (1 + 4 + 8 * self.cap)
 
-    def get_columns(self, first, count):
+    def pack_columns(self, first, count, buf):
         sub = self.o.paths().slice_sites(first, first + count)
         B, cap = self.B, self.cap
         init = sub.init.reshape(B, count).T.copy()
@@ -111,21 +149,58 @@ class OracleDevice:
             for s in range(count):
                 k = cnt[s, b]
                 jp[s, b, :k] = sub.jumps[int(off[b, s]):int(off[b, s]) + k]
-        return np.concatenate([init.reshape(-1).view(np.uint8), cnt.reshape(-1).view(np.uint8),
-                               jp.reshape(-1).view(np.uint8)])
+        packed = np.concatenate([init.reshape(-1).view(np.uint8), cnt.reshape(-1).view(np.uint8),
+                                 jp.reshape(-1).view(np.uint8)])
+        buf.np[:packed.size] = packed
 
-    def put_columns(self, first, count, buf):
+    def unpack_columns(self, first, count, buf):
         B, cap = self.B, self.cap
-        buf = np.ascontiguousarray(buf, dtype=np.uint8)
-        init = buf[:count * B].reshape(count, B)
-        cnt = buf[count * B:count * B * 5].view(np.uint32).reshape(count, B)
-        jp = buf[count * B * 5:].view(np.float64).reshape(count, B, cap)
+        raw = buf.np[:count * self.column_bytes()]
+        init = raw[:count * B].reshape(count, B)
+        cnt = raw[count * B:count * B * 5].view(np.uint32).reshape(count, B)
+        jp = raw[count * B * 5:].view(np.float64).reshape(count, B, cap)
         for s in range(count):
             js = np.concatenate([jp[s, b, :cnt[s, b]] for b in range(B)] + [np.zeros(1)])
             i8 = np.ascontiguousarray(init[s])
             c32 = np.ascontiguousarray(cnt[s])
             self.o.L.orc_set_site(self.o.h, first + s, orc._p(i8, C.c_uint8),
                                   orc._p(c32, C.c_uint32), orc._p(js, C.c_double))
+
+    # ---- statistics rows (the product: epv_run_mcmc_blocks + epv_blocks_to_rows)
+    def run_mcmc_rows(self, burn_in, batch, seed, sweep_base, row_blocks, rows_buf):
+        assert self.left % 256 == 0
+        w = sweep_base
+        for _ in range(burn_in):
+            self._sweep(seed, w)
+            w += 1
+        lo, hi = self._owned()
+        nb = (self.n - self.right + 255) // 256 - self.left // 256
+        n_rows = (nb + row_blocks - 1) // row_blocks
+        V = self.B * 16
+        rows = rows_buf.np[:n_rows * batch * V * 8].view(np.float64).reshape(n_rows, batch, V)
+        one = np.zeros((n_rows, V))
+        nacc = 0
+        for i in range(batch):
+            nacc += self._sweep(seed, w)
+            w += 1
+            self.o.L.orc_suffstats_rows(self.o.h, self.left, 256 * row_blocks, n_rows, lo, hi,
+                                        orc._p(one, C.c_double))
+            rows[:, i, :] = one
+        return nacc
+
+    def reduce_gathered_rows(self, gathered_buf, max_rows, piece_doubles, rows_per_rank, batch, average=True):
+        V = self.B * 16
+        g = gathered_buf.np.view(np.float64)
+        rows = np.concatenate([g[r * piece_doubles:r * piece_doubles + k * batch * V].reshape(k, batch, V)
+                               for r, k in enumerate(rows_per_rank)], axis=0)
+        tot = tree_total(rows)             # [batch][V]
+        acc = np.zeros(V)
+        for i in range(batch):             # the sequential accumulation of run_mcmc
+            acc = acc + tot[i]
+        if average:
+            acc = acc / float(batch)
+        acc = acc.reshape(self.B, 16)
+        return acc[:, :8].reshape(-1).copy(), acc[:, 8:].reshape(-1).copy()
 
     def set_timing(self, on):
         pass

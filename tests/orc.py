@@ -53,6 +53,7 @@ def orc_lib():
         L.orc_mh_site.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
         L.orc_suffstats.argtypes = [C.c_void_p, dp, dp]
         L.orc_suffstats_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, dp, dp]
+        L.orc_suffstats_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, dp]
         L.orc_set_shard.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.orc_sweep_phase.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_uint64] * 4
         L.orc_sweep_phase.restype = C.c_uint64

@@ -180,3 +180,97 @@ def test_est_complete_matches_host_m_step(tmp_path, optimize):
     if optimize:
         t2 = host.Tree.read(d + "/out.nwk")
         np.testing.assert_allclose(t2.branches, br, rtol=1e-5)
+
+
+def _run_em(d, env_extra, tag, args, tree_text=TREE_NWK_TEXT):
+    env = dict(os.environ, **env_extra)
+    cmd = [os.path.join(BIN, "epievo_est_params_histories")] + args + \
+          ["-o", d + "/%s.paths" % tag, "-p", d + "/%s.param" % tag, "-t", d + "/%s.nwk" % tag, "-v",
+           d + "/p.param", d + "/t.nwk", d + "/in.paths"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    tsv = [l for l in r.stderr.split("\n") if l and l[0].isdigit()]
+    layout = [l for l in r.stderr.split("\n") if l.startswith("[GPU LAYOUT")]
+    return (open(d + "/%s.paths" % tag, "rb").read(), open(d + "/%s.param" % tag).read(), tsv,
+            layout[0] if layout else "")
+
+
+@pytest.mark.parametrize("cfg,optimize", [("tree", False), ("bal16", True)])
+def test_em_cli_multi_gpu_rehearsal_is_byte_identical(tmp_path, cfg, optimize):
+    """The C++ sharded EM driver (epv_sampler.cpp): device slots x contexts, halo exchange and
+    the statistics all-gather through the exchange layer.  On the 1-GPU box the slots share
+    device 0 (loopback transport) -- paths file, param file and the -v lines (acceptance rate,
+    log-likelihood) must equal the one-context run byte for byte; one slot with EPV_FORCE_COMM
+    drives the same path through a one-rank RCCL communicator (ncclCommInitAll, ncclAllGather)."""
+    n = 14000 if cfg == "tree" else 9000
+    model, tree, fp = simulate(cfg, n, seed=23)
+    d = str(tmp_path)
+    open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT if cfg == "tree" else _newick(tree))
+    host.write_paths(d + "/in.paths", tree.node_names, tree.branches, fp)
+    args = ["-i", "3", "-B", "4", "-L", "3", "-s", "5"] + (["-b"] if optimize else [])
+    one = _run_em(d, {"EPV_CONTEXTS_PER_GPU": "1", "EPV_DEVICES": "0"}, "one", args)
+    assert "1 context" in one[3]
+    # 3 slots x 2 contexts on device 0, rows of 4 blocks (cut points on multiples of 1024 sites)
+    reh = _run_em(d, {"EPV_CONTEXTS_PER_GPU": "2", "EPV_DEVICES": "0,0,0", "EPV_ROW_BLOCKS": "4"}, "reh", args)
+    assert "3 GPU slot(s)" in reh[3] and "loopback" in reh[3] and "= 6 parts" in reh[3]
+    assert reh[:3] == one[:3]
+    # the -g flag instead of the environment, 2 slots x 1 context
+    flag = _run_em(d, {"EPV_CONTEXTS_PER_GPU": "1", "EPV_ROW_BLOCKS": "2"}, "flag", args + ["-g", "0,0"])
+    assert "2 GPU slot(s)" in flag[3] and flag[:3] == one[:3]
+    # RCCL itself, one rank: communicator set-up, all-gather, tear-down on hardware
+    rccl = _run_em(d, {"EPV_CONTEXTS_PER_GPU": "2", "EPV_DEVICES": "0", "EPV_FORCE_COMM": "1", "EPV_ROW_BLOCKS": "4"},
+                   "rccl", args)
+    assert "RCCL" in rccl[3] and rccl[:3] == one[:3]
+
+
+def test_em_cli_long_chain_two_contexts(tmp_path):
+    """-L 50 -B 50 (100 sweeps between halo refreshes): the internal halo is sized from the chain
+    length, so the default two-context mode runs it and equals the one-context run"""
+    model, tree, fp = simulate("tree", 6000, seed=29)
+    d = str(tmp_path)
+    open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+    host.write_paths(d + "/in.paths", tree.node_names, tree.branches, fp)
+    args = ["-i", "1", "-B", "50", "-L", "50", "-s", "11"]
+    one = _run_em(d, {"EPV_CONTEXTS_PER_GPU": "1"}, "one", args)
+    two = _run_em(d, {"EPV_CONTEXTS_PER_GPU": "2"}, "two", args)
+    assert "halo 768" in two[3] and "= 2 parts" in two[3]
+    assert two[:3] == one[:3]
+
+
+@pytest.mark.parametrize("optimize", [False, True])
+def test_initialization_output_feeds_the_em_driver(tmp_path, optimize):
+    """the README pipeline: epievo_initialization ... tree obs -> epievo_est_params_histories
+    init.param tree init.paths.  Without -b the paths carry rate-scaled tot_times next to the
+    unscaled tree; with -b the updated tree is printed at 6 significant digits.  Both are
+    ordinary inputs (the reference compares nothing): the driver rescales and runs."""
+    model, tree, fp = simulate("tree", 3000, seed=33)
+    d = str(tmp_path)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+    B, n, N = tree.n_nodes - 1, fp.n_sites, tree.n_nodes
+    es = fp.init.reshape(B, n) ^ (fp.counts().reshape(B, n) & 1).astype(np.uint8)
+    leaves = [i for i in range(N) if tree.subtree_sizes[i] == 1]
+    with open(d + "/obs.states", "w") as f:
+        f.write("#" + "\t".join(tree.node_names[i] for i in leaves) + "\n")
+        for s in range(n):
+            f.write("%d\t%s\n" % (s, "\t".join(str(es[i - 1, s]) for i in leaves)))
+    cmd = [os.path.join(BIN, "epievo_initialization"), "-i", "3", "-B", "2", "-s", "5", "-p", d + "/init.param",
+           "-o", d + "/init.paths", "-t", d + "/init.nwk"] + (["-b"] if optimize else [])
+    r = subprocess.run(cmd + [d + "/t.nwk", d + "/obs.states"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    tree_in = d + "/init.nwk" if optimize else d + "/t.nwk"
+    r = subprocess.run([os.path.join(BIN, "epievo_est_params_histories"), "-i", "2", "-B", "3", "-L", "2", "-s", "7",
+                        "-o", d + "/out.paths", "-p", d + "/out.param", "-v", d + "/init.param", tree_in,
+                        d + "/init.paths"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "RESCALING PATHS" in r.stderr
+    out, names, tt = host.read_paths(d + "/out.paths")
+    es2 = out.init.reshape(B, n) ^ (out.counts().reshape(B, n) & 1).astype(np.uint8)
+    assert np.array_equal(es2[[i - 1 for i in leaves]], es[[i - 1 for i in leaves]])   # leaf data kept
+    t_in = host.Tree.read(tree_in)
+    for b in range(1, N):          # every jump inside its (final) branch
+        jb = out.jumps[int(out.offsets[(b - 1) * n]):int(out.offsets[b * n])]
+        assert jb.size == 0 or (jb.min() > 0 and jb.max() < tt[b])
+    assert np.all(np.isfinite(host.Model.read(d + "/out.param", scale=True).rates))
+    assert len(t_in.branches) == N

@@ -1,5 +1,6 @@
 """The N>1 path: site shards with wide halos (epievo_amd/parallel.py) must reproduce the
-unsharded run bit-for-bit on paths and J (D up to cross-shard summation order).
+unsharded run bit-for-bit on paths, J, D and the acceptance rate (shards are cut on whole rows of
+the statistics tree, so every rank sums the same balanced tree as one context does).
 CPU: 2 and 3 gloo ranks over the oracle-backed device double.  GPU: 2 gloo ranks sharing
 the one MI355X through the real HIP path."""
 import os
@@ -12,7 +13,7 @@ import pytest
 
 import orc
 from common import simulate
-from epievo_amd.parallel import concat_sites
+from epievo_amd.parallel import concat_sites, halo_width, shard_cuts
 from epievo_amd.host import FlatPaths
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,7 +26,7 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _run_ranks(world, backend, cfg, n_own, burn, batch, iters, port=None):
+def _run_ranks(world, backend, cfg, n_global, burn, batch, iters, row_blocks=1):
     port = _free_port()      # a fixed port can still be in TIME_WAIT from the previous run
     out = tempfile.mkdtemp(prefix="epv_shard_")
     procs = []
@@ -33,8 +34,8 @@ def _run_ranks(world, backend, cfg, n_own, burn, batch, iters, port=None):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LOCAL_RANK=str(r), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen(
-            [sys.executable, os.path.join(HERE, "dist_worker.py"), backend, cfg, str(n_own),
-             str(burn), str(batch), str(iters), out], env=env))
+            [sys.executable, os.path.join(HERE, "dist_worker.py"), backend, cfg, str(n_global),
+             str(burn), str(batch), str(iters), out, str(row_blocks)], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
     return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
@@ -72,22 +73,34 @@ class _OracleEngine:
         return self.o.paths()
 
 
-def _check(ranks, ref_res, ref_paths, n_nodes, n_own):
-    parts = [FlatPaths(n_own, n_nodes, r["init"], r["offsets"], r["jumps"]) for r in ranks]
+def _check(ranks, ref_res, ref_paths, n_nodes, cuts):
+    parts = [FlatPaths(cuts[i + 1] - cuts[i], n_nodes, r["init"], r["offsets"], r["jumps"])
+             for i, r in enumerate(ranks)]
     assert orc.paths_equal(concat_sites(parts), ref_paths)
     for it, (J, D, acc) in enumerate(ref_res):
         for r in ranks:
             assert np.array_equal(r["J%d" % it], J)
-            np.testing.assert_allclose(r["D%d" % it], D, rtol=1e-12)
+            assert np.array_equal(r["D%d" % it], D)       # same balanced tree, same bits
             assert float(r["acc%d" % it]) == acc
 
 
-@pytest.mark.parametrize("world,cfg,n_own", [(2, "tree", 400), (3, "pair", 300)])
-def test_sharded_oracle_gloo(world, cfg, n_own):
+# shards of unequal length (the cut points sit on whole rows), 1- and 4-block rows
+@pytest.mark.parametrize("world,cfg,n,row_blocks", [(2, "tree", 1500, 1), (3, "pair", 2300, 1), (2, "tree", 4000, 4)])
+def test_sharded_oracle_gloo(world, cfg, n, row_blocks):
     burn, batch, iters = 1, 3, 2
-    ranks = _run_ranks(world, "oracle", cfg, n_own, burn, batch, iters, 29611 + world)
-    ref_res, ref_paths, tree = _unsharded(_OracleEngine, cfg, n_own * world, burn, batch, iters)
-    _check(ranks, ref_res, ref_paths, tree.n_nodes, n_own)
+    ranks = _run_ranks(world, "oracle", cfg, n, burn, batch, iters, row_blocks)
+    ref_res, ref_paths, tree = _unsharded(_OracleEngine, cfg, n, burn, batch, iters)
+    _check(ranks, ref_res, ref_paths, tree.n_nodes, shard_cuts(n, world, row_blocks))
+
+
+def test_shard_cuts_and_halo_width():
+    assert halo_width(60) == 512 and halo_width(1) == 256 and halo_width(100) == 768
+    cuts = shard_cuts(10 ** 7, 8)
+    assert cuts[0] == 0 and cuts[-1] == 10 ** 7 and all(c % 16384 == 0 for c in cuts[1:-1])
+    lens = np.diff(cuts)
+    assert lens.max() - lens.min() <= 2 * 16384
+    with pytest.raises(ValueError):
+        shard_cuts(20000, 4)
 
 
 @pytest.mark.gpu
@@ -113,10 +126,11 @@ def test_sharded_hip_two_ranks_one_gpu():
         def paths(self):
             return self.d.paths()
 
-    burn, batch, iters, n_own = 2, 3, 2, 5000
-    ranks = _run_ranks(2, "hip", "tree", n_own, burn, batch, iters, 29655)
-    ref_res, ref_paths, tree = _unsharded(_HipEngine, "tree", 2 * n_own, burn, batch, iters)
-    _check(ranks, ref_res, ref_paths, tree.n_nodes, n_own)
+    burn, batch, iters, n, rb = 2, 3, 2, 10000, 4
+    ranks = _run_ranks(2, "hip", "tree", n, burn, batch, iters, rb)
+    ref_res, ref_paths, tree = _unsharded(_HipEngine, "tree", n, burn, batch, iters)
+    cuts = shard_cuts(n, 2, rb)
+    _check(ranks, ref_res, ref_paths, tree.n_nodes, cuts)
     # the same with two concurrent contexts per rank (LocalGroup inside each rank's shard)
-    ranks = _run_ranks(2, "hipgroup", "tree", n_own, burn, batch, iters, 29657)
-    _check(ranks, ref_res, ref_paths, tree.n_nodes, n_own)
+    ranks = _run_ranks(2, "hipgroup", "tree", n, burn, batch, iters, rb)
+    _check(ranks, ref_res, ref_paths, tree.n_nodes, cuts)

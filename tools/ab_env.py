@@ -7,7 +7,7 @@ cfg, n, envs = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
 code = r'''
 import sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
-from common import simulate
+from epievo_amd.workloads import simulate
 from epievo_amd.sampler import DeviceSampler
 model, tree, fp = simulate(%r, %d, seed=42)
 d = DeviceSampler(0); d.set_tree(tree); d.set_model(model); d.upload_paths(fp, 0 if %r == "pair" else 16); d.reset()

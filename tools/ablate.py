@@ -32,7 +32,7 @@ import sys, time
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 from epievo_amd import _build
 _build.HIP_SO = %r
-from common import simulate
+from epievo_amd.workloads import simulate
 from epievo_amd.sampler import DeviceSampler
 model, tree, fp = simulate(%r, %d, seed=42)
 d = DeviceSampler(0); d.set_tree(tree); d.set_model(model); d.upload_paths(fp, 16); d.reset()

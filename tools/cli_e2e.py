@@ -4,7 +4,7 @@ import os, subprocess, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np
-from common import simulate, TEST_PARAM_TEXT, TREE_NWK_TEXT
+from epievo_amd.workloads import simulate, TEST_PARAM_TEXT, TREE_NWK_TEXT
 from epievo_amd import host, _build
 d = tempfile.mkdtemp()
 open(d + "/p.param", "w").write(TEST_PARAM_TEXT); open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)

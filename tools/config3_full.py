@@ -3,7 +3,7 @@ epievo_est_params_histories -i 20 -B 50 (-L 10), file IO included."""
 import os, subprocess, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
-from common import simulate, TEST_PARAM_TEXT, TREE_NWK_TEXT
+from epievo_amd.workloads import simulate, TEST_PARAM_TEXT, TREE_NWK_TEXT
 from epievo_amd import host, _build
 d = tempfile.mkdtemp()
 open(d + "/p.param", "w").write(TEST_PARAM_TEXT); open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)

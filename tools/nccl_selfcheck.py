@@ -13,7 +13,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from common import ref_test_model, config          # noqa: E402
+from epievo_amd.workloads import ref_test_model, config          # noqa: E402
 from epievo_amd import host                        # noqa: E402
 from epievo_amd.parallel import ShardedSampler, TorchComm   # noqa: E402
 

@@ -1,6 +1,6 @@
 import sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
-from common import simulate
+from epievo_amd.workloads import simulate
 from epievo_amd.sampler import DeviceSampler
 for cfg, n in (("tree", 1000000), ("pair", 100000), ("pair", 1000000), ("bal16", 200000)):
     model, tree, fp = simulate(cfg, n, seed=42)

@@ -3,7 +3,7 @@
 kernels fill the idle issue slots?"""
 import sys, time, threading
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
-from common import simulate
+from epievo_amd.workloads import simulate
 from epievo_amd.sampler import DeviceSampler
 n = 1000000
 for k in (1, 2, 3, 4):

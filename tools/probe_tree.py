@@ -1,6 +1,6 @@
 import sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
-from common import simulate
+from epievo_amd.workloads import simulate
 from epievo_amd.sampler import DeviceSampler
 cfg = sys.argv[1] if len(sys.argv) > 1 else "tree"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000

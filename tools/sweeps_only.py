@@ -3,7 +3,7 @@
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
-from common import simulate
+from epievo_amd.workloads import simulate
 from epievo_amd.sampler import DeviceSampler
 cfg, n = sys.argv[1], int(sys.argv[2])
 model, tree, fp = simulate(cfg, n, seed=42)
