@@ -214,10 +214,28 @@ def main():
     ss.dev.set_timing(False)
     avg_ms, n_launch = ss.dev.kernel_time_ms()
 
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    def rank_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        return float(t.item())
+
+    el = rank_max(el)
+
+    # the same steps with the proposal ratio q(old)/q(new) evaluated by the reference's sums
+    # (EPV_OPT_REFERENCE_PROPOSAL_RATIO) instead of the exact 0 they amount to: reported beside
+    # the headline so that the cost of that arithmetic -- which changes no path -- is on record
+    ss.dev.set_options(reference_proposal_ratio=True)
+    k_ref = max(1, min(2, args.steps))
+    step(args.warmup + args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(k_ref):
+        step(args.warmup + args.steps + 1 + i)
+    barrier()
+    el_ref = rank_max(time.perf_counter() - t0)
+    ss.dev.set_options()
 
     B = tree.n_nodes - 1
     owned_total = n_global - 2
@@ -237,6 +255,28 @@ def main():
                 traffic = json.load(open(tj)).get(args.config, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what really bounds these kernels: VALU issue.  Instruction counts per launch come from
+        # the committed PMC profile of this workload (profiles/issue.json, rocprofv3 --pmc
+        # SQ_INSTS_VALU ...; they are properties of the code and the data, not of the box)
+        issue = None
+        ij = os.path.join(ROOT, "profiles", "issue.json")
+        if os.path.exists(ij) and avg_ms > 0:
+            try:
+                q = json.load(open(ij)).get(args.config)
+                if q:
+                    # the profile was taken with one context per GPU: scale to this launch's sites
+                    insts = q["valu_wave_insts_per_launch"] * per_launch_units / q["resamples_per_launch"]
+                    bound_ms = insts * q["cycles_per_inst"] / (q["simds"] * q["clock_ghz"] * 1e9) * 1e3
+                    issue = {"bound": "valu-issue", "valu_wave_insts_per_launch": insts,
+                             "cycles_per_inst": q["cycles_per_inst"], "simds": q["simds"],
+                             "clock_ghz": q["clock_ghz"], "bound_ms_per_launch": bound_ms,
+                             "measured_ms_per_launch": avg_ms, "concurrent_launches": k_eff,
+                             # k_eff launches share the SIMDs: the device issues k_eff * insts in avg_ms
+                             "frac": k_eff * bound_ms / avg_ms, "lane_utilisation": q.get("lane_utilisation"),
+                             "source": "profiles/%s_pmc_valu_%s.csv" % (q["round"], args.config)}
+            except Exception:
+                issue = None
+        achieved_device = achieved * k_eff
         out = {
             "metric": "site-branch path resamples/sec at n=1e6, 4-leaf tree",
             "value": value, "unit": "site-branch resamples/s", "n_gpus": world,
@@ -249,18 +289,26 @@ def main():
                        else "%s, n=%d per GPU" % (args.config, n_local),
                        "sites_per_gpu": n_local, "branches": B, "burn_in": BURN_IN, "batch": BATCH,
                        "mean_jumps_per_path": kbar, "shards_per_gpu": k_eff,
-                       "sharding": "contiguous site shards, %d-column redundant halos refreshed once per step, "
+                       "sharding": "contiguous site shards cut on 16384-site rows of the statistics tree, "
+                                   "%d-column redundant halos refreshed once per step, "
                                    "%d GPU shard(s) x %d concurrent context(s) per GPU" % (ss.halo, world, k_eff)},
-            "roofline": {"bound": "hbm", "kernel": "epv_mh_propose_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel (one colour phase = one timed launch triple)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # frac = what the DEVICE sustains: k_eff launches (one per context of this GPU) run
+            # concurrently, each timed with its own HIP events on its own stream
+            "roofline": {"bound": "hbm", "kernel": "epv_mh_propose_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel (one colour phase = one timed launch triple)",
+                         "achieved": achieved_device,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_device / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_resample": bytes_per,
                          "resamples_per_launch": per_launch_units, "avg_launch_ms": avg_ms,
-                         "launches_timed": n_launch,
-                         # k_eff such launches (one per context of this GPU) run concurrently: what
-                         # the DEVICE sustains is k_eff times the per-launch figure
-                         "concurrent_launches": k_eff, "achieved_device": achieved * k_eff,
-                         "frac_device": achieved * k_eff / HBM_PEAK_GBS},
+                         "launches_timed": n_launch, "concurrent_launches": k_eff,
+                         "achieved_per_launch": achieved, "issue": issue},
         }
+        out["config"]["proposal_ratio"] = ("exact (q(old)/q(new) = 1 when the root state is kept: "
+                                           "DESIGN.md section 4.1); same paths as the reference's sums")
+        out["reference_proposal_arithmetic"] = {
+            "value": float(k_ref) * (BURN_IN + BATCH) * owned_total * B / el_ref, "unit": "site-branch resamples/s",
+            "ms_per_step": el_ref / k_ref * 1e3, "steps": k_ref,
+            "note": "EPV_OPT_REFERENCE_PROPOSAL_RATIO: the two log-probability sums of "
+                    "SingleSiteSampler.cpp:180-339 evaluated as the reference does"}
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(model, tree, fp_own)
         sys.stdout.flush()

@@ -249,14 +249,14 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     ++c->ev_used;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
   }
-  if (c->mh_gpool)
-    hipLaunchKernelGGL(epv_mh_propose_kernel<true>, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds,
-                       c->stream, c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       sweep, first, last, c->pool_entries, c->d_counters, c->d_gpool);
-  else
-    hipLaunchKernelGGL(epv_mh_propose_kernel<false>, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds,
-                       c->stream, c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       sweep, first, last, c->pool_entries, c->d_counters, (double *)nullptr);
+  {
+    const bool refq = c->S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO;
+    auto kern = c->mh_gpool ? (refq ? epv_mh_propose_kernel<true, true> : epv_mh_propose_kernel<true, false>)
+                            : (refq ? epv_mh_propose_kernel<false, true> : epv_mh_propose_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds, c->stream, c->S,
+                       (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last,
+                       c->pool_entries, c->d_counters, c->mh_gpool ? c->d_gpool : (double *)nullptr);
+  }
   {
     // one lane per dirty (site, branch) pair; the count is only known on the device, so
     // launch a grid that covers the typical case and grid-stride over the rest
@@ -329,9 +329,13 @@ EPV_API epv_ctx *epv_create(int device_id) {
     return nullptr;
   }
   // the MH kernel asks for more dynamic LDS than the 64 KiB default
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<false>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<true>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return c;
 }
@@ -466,6 +470,21 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
 }
 
 static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base);
+
+EPV_API int epv_set_options(epv_ctx *c, uint32_t flags) {
+  if (!c) return EPV_ERR_ARG;
+  if (flags & ~(uint32_t)(EPV_OPT_REFERENCE_PROPOSAL_RATIO | EPV_OPT_FORWARD_REJECTION))
+    return fail(c, EPV_ERR_ARG, "unknown option bits");
+  static_assert(EPV_OPT_REFERENCE_PROPOSAL_RATIO == EPV_FLAG_REFERENCE_PROPOSAL_RATIO &&
+                EPV_OPT_FORWARD_REJECTION == EPV_FLAG_FORWARD_REJECTION, "option bits");
+  c->S.flags = flags;
+  return EPV_OK;
+}
+EPV_API int epv_get_options(epv_ctx *c, uint32_t *flags) {
+  if (!c || !flags) return EPV_ERR_ARG;
+  *flags = c->S.flags;
+  return EPV_OK;
+}
 
 EPV_API int epv_get_capacity(epv_ctx *c, uint32_t *capacity) {
   if (!c || !capacity || !c->have_paths) return EPV_ERR_ARG;

@@ -49,6 +49,7 @@ struct EpvDev {
   uint64_t phase_cap;  // max sites of one colour phase; the hand-over arrays are indexed by
                        // the phase-local thread id (site = s0 + 3*tid) so they are written densely
   uint32_t W;        // 64-bit words per (site, branch) in prop_states = ceil((2C+1)/64)
+  uint32_t flags;    // EPV_OPT_* (epv_set_options)
   const EpvModelConst *model;  // device copy
   const uint32_t *parent;      // [N]
   const uint32_t *subtree;     // [N]
@@ -62,6 +63,10 @@ struct EpvIndepConst {
   double P[4];                     // continuous_time_trans_prob_mat(r0, r1, branch length)
   double J0[4], J1[4], D0[4], D1[4];  // expectation_J / expectation_D
 };
+
+// run-time options (epv_set_options; the same values as the public header)
+#define EPV_FLAG_REFERENCE_PROPOSAL_RATIO 1u  /* evaluate q(old)/q(new) with the reference's sums */
+#define EPV_FLAG_FORWARD_REJECTION 2u         /* state-changing segments by forward rejection too */
 
 // counters[] slots
 enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_TASKS2 = 4, EPV_CNT_N = 5 };

@@ -229,14 +229,14 @@ __device__ __forceinline__ int run_trial(uint32_t seed_lo, uint32_t seed_hi, uin
                                          double u0, uint32_t a0, uint32_t end, double T, double r0,
                                          double r1, double nojump0, double nojump1, double trunc,
                                          uint32_t room, double *dst, uint64_t stride, uint32_t max_store,
-                                         double start_time, uint32_t &nj_out) {
+                                         double start_time, uint32_t &nj_out, bool nielsen = true) {
   nj_out = 0;
   uint32_t nj = 0, a = a0, d = 0;
   double tau = 0.0;
   epv_block2 blk;
   blk.d0 = 0.0; blk.d1 = 0.0;
   double u = u0;
-  if (a0 != end) {
+  if (nielsen && a0 != end) {
     tau = -epv_log(1.0 - u0 * trunc) / (a0 ? r1 : r0);
     if (!(tau < T)) return TRIAL_FAIL;   // a draw within rounding of 1: redraw (oracle: same guard)
     if (room == 0u) return TRIAL_OVERFLOW;
@@ -248,7 +248,7 @@ __device__ __forceinline__ int run_trial(uint32_t seed_lo, uint32_t seed_hi, uin
     d = 1u;
     if (1.0 - u < (a ? nojump1 : nojump0)) { nj_out = 1u; return TRIAL_OK; }   // a == end now
   } else if (1.0 - u0 < (a0 ? nojump1 : nojump0)) {
-    return TRIAL_OK;
+    return a0 == end ? TRIAL_OK : TRIAL_FAIL;   // no jump: the state is kept (a flip only in forward mode)
   }
   int outcome;
   for (;;) {
@@ -293,10 +293,13 @@ __device__ __forceinline__ int scan_trials(uint32_t seed_lo, uint32_t seed_hi, u
                                            uint32_t W, uint32_t a0, uint32_t end, double T, double r0,
                                            double r1, double trunc, uint32_t room, double *dst,
                                            uint64_t stride, uint32_t max_store, double start_time,
-                                           uint32_t &t_out, uint32_t &nj_out) {
-  const bool flip = a0 != end;
-  // no-(further-)jump bound of the state the chain waits in: a0, or `end` after the first jump
-  const double bound = nojump_bound(T * (end ? r1 : r0));
+                                           uint32_t &t_out, uint32_t &nj_out, bool nielsen = true) {
+  // flip: the segment changes state AND is sampled by Nielsen's method (forward-rejection mode,
+  // EPV_FLAG_FORWARD_REJECTION, treats such a segment like any other: a trial must END in `end`)
+  const bool flip = nielsen && a0 != end;
+  const bool keep = a0 == end;
+  // no-(further-)jump bound of the state the chain waits in: a0, or `end` after Nielsen's first jump
+  const double bound = nojump_bound(T * ((flip ? end : a0) ? r1 : r0));
   uint32_t t = t0;
   const uint32_t t_end = t0 + W;
   nj_out = 0;
@@ -317,7 +320,8 @@ __device__ __forceinline__ int scan_trials(uint32_t seed_lo, uint32_t seed_hi, u
         u = (t & 1u) ? fb.d1 : fb.d0;
       }
       if (!flip && 1.0 - u < bound) {     // provably no jump in this trial: the state is kept
-        t_out = t; nj_out = 0; return TRIAL_OK;
+        if (keep) { t_out = t; nj_out = 0; return TRIAL_OK; }
+        continue;                         // forward mode, state must change: this trial fails
       }
       cand = true;
       break;
@@ -325,7 +329,7 @@ __device__ __forceinline__ int scan_trials(uint32_t seed_lo, uint32_t seed_hi, u
     if (!cand) return TRIAL_FAIL;
     const double nb = flip ? bound : 0.0;
     const int oc = run_trial(seed_lo, seed_hi, gsite, sweep, node, k, t, u, a0, end, T, r0, r1, nb, nb,
-                             trunc, room, dst, stride, max_store, start_time, nj_out);
+                             trunc, room, dst, stride, max_store, start_time, nj_out, nielsen);
     if (oc != TRIAL_FAIL) { t_out = t; return oc; }
     ++t;
   }
@@ -371,7 +375,18 @@ __device__ __forceinline__ double gtp(double r0, double r1, double h, double den
 #ifndef EPV_PROPOSE_WAVES
 #define EPV_PROPOSE_WAVES 3   /* waves per SIMD the register allocation aims for (<= 168 VGPRs) */
 #endif
-template <bool GPOOL>
+// REFQ = true : q(old)/q(new) evaluated as the reference does (downward_sampling_branch and
+//   proposal_prob_branch, SingleSiteSampler.cpp:180-255, :272-339: per segment
+//   log P(end | start, data) - log PT(start -> end), for the proposal and for the current path).
+// REFQ = false: that ratio is 1 EXACTLY when the root state is not resampled (SAMPLE_ROOT is
+//   hard-wired false, :441): per segment the term is log(p[k+1][end] / p[k][start]), which
+//   telescopes along a branch and over the tree to minus the log of the proposal's normalising
+//   constant prod_{c child of root} p_c[0][root state] -- a function of the neighbours and the
+//   leaf data, not of the path.  The reference's own sums differ from 0 by rounding only
+//   (<= 2e-12 over millions of updates, tests/test_proposal_ratio.py), and both modes produce
+//   the same paths.  The default; the kernel then needs no log, no current-path walk and no
+//   prop_llr hand-over.
+template <bool GPOOL, bool REFQ>
 __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
     uint64_t first, uint64_t last, uint32_t pool_entries, unsigned long long *counters,
@@ -504,7 +519,9 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
           const uint32_t off = regA[node * 64u + lane];
           const uint32_t par = S.parent[node];
           const uint32_t start_state = (par == 0u) ? root_state : (regA[par * 64u + lane] >> 31);
-          const PathRef cur = path_ref(S, selM, b, site);
+          PathRef cur;
+          cur.j = nullptr; cur.nj = 0; cur.init = 0;
+          if (REFQ) cur = path_ref(S, selM, b, site);
           uint32_t prev = start_state;
           bool clean = true;
           unsigned long long word = 0ull;
@@ -533,14 +550,16 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
             const double p0 = PT0 * nxt0 / (prev ? pk1 : pk0);
             const epv_block2 sblk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, k, 0u, 0u);
             const uint32_t sampled = (sblk.d0 > p0) ? 1u : 0u;
-            log_prob += (sampled == 0u) ? epv_log(p0) : epv_log(1.0 - p0);
-            log_prob -= epv_log(gtp(r0, r1, h, denom, prev, sampled));
+            if (REFQ) {
+              log_prob += (sampled == 0u) ? epv_log(p0) : epv_log(1.0 - p0);
+              log_prob -= epv_log(gtp(r0, r1, h, denom, prev, sampled));
+            }
             // trial 1's first draw is the other half of the same Philox block
             clean = clean && (sampled == prev) &&
                     (1.0 - sblk.d1 < nojump_bound(len * (prev ? r1 : r0)));
             word |= (unsigned long long)sampled << (k & 63u);
             if ((k & 63u) == 63u) { states[k >> 6] = word; word = 0ull; }
-#ifndef EPV_ABLATE_CURPATH
+            if (REFQ) {
             // current path: where does it stand at the end of this segment
             end_time += len;
             while (ej < cur.nj && cur_next < end_time) {
@@ -554,7 +573,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
             lp += (cs_end == 0u) ? epv_log(p0c) : epv_log(1.0 - p0c);
             sj = ej;
             cs_start = cs_end;
-#endif
+            }
             prev = sampled;
             pk0 = nxt0; pk1 = nxt1;
             if (!last) {
@@ -619,7 +638,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
 
     // ---- hand-over to epv_mh_accept_kernel: q(old) - q(new) and the overflow flag
     if (run) {
-      S.prop_llr[tid] = orig_proposal - log_prob;
+      if (REFQ) S.prop_llr[tid] = orig_proposal - log_prob;
       S.prop_flag[tid] = 0u;
       pending = false;
     }
@@ -665,6 +684,7 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
   uint32_t *c_misc = c_misc_[wave], *c_gsite = c_gsite_[wave], *c_tbase = c_tbase_[wave],
            *c_nk = c_nk_[wave], *c_res = c_res_[wave], *c_tw = c_tw_[wave];
   const bool indep = indep_r0 > 0.0;   // epv_indep_update_paths: rates are not context dependent
+  const bool nielsen = !(S.flags & EPV_FLAG_FORWARD_REJECTION);
   const uint32_t shard = blockIdx.y;   // one task-list region per counter shard
   // two regions per shard, each filled from both ends: buckets K = 1, 2, 3, >= 4 in this order
   const unsigned long long packed = counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)];
@@ -739,7 +759,7 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
           uint32_t njt, tw;
           const int oc = scan_trials(seed_lo, seed_hi, gsite, sweep, node, k, 1u, EPV_INLINE_TRIALS, prev,
                                      sampled, len, r0, r1, trunc, C - cnt, dst + (uint64_t)cnt * n, n,
-                                     0xffffffffu, time_passed, tw, njt);
+                                     0xffffffffu, time_passed, tw, njt, nielsen);
           if (oc == TRIAL_OK) cnt += njt;
           else if (oc == TRIAL_OVERFLOW) ovf = true;
           else pend = true;
@@ -777,7 +797,7 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
           uint32_t njt, tw = 0u;
           oc = scan_trials(seed_lo, seed_hi, t_site, sweep, nk >> 12, nk & 4095u, t0, EPV_COOP_WINDOW,
                            misc & 1u, (misc >> 1) & 1u, t_len, t_r0, t_r1, t_trunc, misc >> 8,
-                           c_tj + (size_t)lane * EPV_TJ, 1u, EPV_TJ, 0.0, tw, njt);
+                           c_tj + (size_t)lane * EPV_TJ, 1u, EPV_TJ, 0.0, tw, njt, nielsen);
           c_tw[lane] = tw;
           c_res[lane] = (uint32_t)oc | (njt << 8);
         }
@@ -802,7 +822,7 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
                                                       EPV_FIRST_DRAW_BLOCK);
                 uint32_t nj2;
                 run_trial(seed_lo, seed_hi, gsite, sweep, node, k, tw, (tw & 1u) ? fb.d1 : fb.d0, prev,
-                          sampled, len, r0, r1, 0.0, 0.0, trunc, C - cnt, d2, n, 0xffffffffu, time_passed, nj2);
+                          sampled, len, r0, r1, 0.0, 0.0, trunc, C - cnt, d2, n, 0xffffffffu, time_passed, nj2, nielsen);
               }
               cnt += njt;
             } else {
@@ -874,7 +894,7 @@ __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
     double llh_l = S.tri[site - 1];
     double llh_m = S.tri[site];
     double llh_r = S.tri[site + 1];
-    double llr = S.prop_llr[tid];
+    double llr = (S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO) ? S.prop_llr[tid] : 0.0;
     const double llh_l_orig = llh_l, llh_r_orig = llh_r;
     if (!ovf) {
       // the three triples centred at site-1, site, site+1 with the proposal standing in

@@ -576,6 +576,10 @@ class LocalGroup:
         for s in self.subs:
             s.set_timing(on)
 
+    def set_options(self, **kw):
+        for s in self.subs:
+            s.set_options(**kw)
+
     def kernel_time_ms(self):
         """launch-weighted mean duration of the shards' colour-phase launches, and their number"""
         tot, n = 0.0, 0

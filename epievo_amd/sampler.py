@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "epv_get_columns", "epv_put_columns", "epv_copy_columns", "epv_dev_alloc", "epv_dev_free",
     "epv_run_mcmc_blocks", "epv_reduce_blocks", "epv_get_counters", "epv_kernel_time_ms",
     "epv_set_timing", "epv_pack_columns_dev", "epv_unpack_columns_dev", "epv_device_of",
-    "epv_blocks_to_rows", "epv_reduce_rows", "epv_reduce_gathered_rows", "epv_dev_write", "epv_dev_read",
+    "epv_blocks_to_rows", "epv_reduce_rows", "epv_reduce_gathered_rows", "epv_dev_write", "epv_dev_read", "epv_set_options", "epv_get_options",
 ]
 
 
@@ -105,6 +105,8 @@ def lib():
         L.epv_reduce_rows.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, dp, dp]
         L.epv_reduce_gathered_rows.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u64p, C.c_uint64, C.c_int,
                                                dp, dp]
+        L.epv_set_options.argtypes = [vp, C.c_uint32]
+        L.epv_get_options.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.epv_dev_write.argtypes = [vp, vp, vp, C.c_uint64]
         L.epv_dev_read.argtypes = [vp, vp, vp, C.c_uint64]
         L.epv_get_counters.argtypes = [vp, C.POINTER(_Counters)]
@@ -183,6 +185,11 @@ class DeviceSampler:
                 self.capacity_events.append(msg)
                 return
         self._ck(rc)
+
+    def set_options(self, reference_proposal_ratio=False, forward_rejection=False):
+        """see EPV_OPT_* in include/epievo_mi355x.h"""
+        self._ck(self.L.epv_set_options(self.h, (1 if reference_proposal_ratio else 0) |
+                                        (2 if forward_rejection else 0)))
 
     def capacity(self):
         v = C.c_uint32(0)

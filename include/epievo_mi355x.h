@@ -50,6 +50,22 @@ typedef struct {
   uint64_t reserved;
 } epv_counters;
 
+/* Run-time options of a context (epv_set_options; default 0).
+ * EPV_OPT_REFERENCE_PROPOSAL_RATIO  evaluate the proposal ratio q(old)/q(new) of
+ *     Metropolis_Hastings_site with the reference's sums (downward_sampling_branch,
+ *     SingleSiteSampler.cpp:180-225, and proposal_prob_branch, :272-314).  With SAMPLE_ROOT false
+ *     (hard-wired, :441) that ratio is EXACTLY 1: per segment the reference accumulates
+ *     log(p[k+1][end] / p[k][start]), which telescopes along every branch and over the tree to the
+ *     log of the proposal's normalising constant -- independent of the path.  The reference's
+ *     value differs from 0 by rounding only; by default the kernels use the exact 0 and skip
+ *     the sums (same paths, same statistics; tests/test_proposal_ratio.py).
+ * EPV_OPT_FORWARD_REJECTION  sample state-changing segments by forward rejection
+ *     (end_cond_sample_forward_rejection, EndCondSampling.cpp:479-509, the sampler the
+ *     reference's hot path calls) instead of the reference library's
+ *     end_cond_sampling_Nielsen (:576-617), the default here because its acceptance probability
+ *     does not vanish on short branches.  Same conditional law; for parity tests. */
+enum { EPV_OPT_REFERENCE_PROPOSAL_RATIO = 1, EPV_OPT_FORWARD_REJECTION = 2 };
+
 /* Create a context on HIP device `device_id`.  Returns NULL when the device cannot be
  * initialised (the product has no CPU fallback).  Replaces
  * SingleSiteSampler::SingleSiteSampler (SingleSiteSampler.cpp:439-447). */
@@ -87,6 +103,8 @@ int epv_upload_paths(epv_ctx *ctx, uint64_t n_sites, const uint8_t *init_state,
  * resident path has more jumps than `capacity`; capacity is clamped to 1..127. */
 int epv_set_capacity(epv_ctx *ctx, uint32_t capacity);
 int epv_get_capacity(epv_ctx *ctx, uint32_t *capacity);
+int epv_set_options(epv_ctx *ctx, uint32_t flags);
+int epv_get_options(epv_ctx *ctx, uint32_t *flags);
 
 /* initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device, for the
  * two-node tree of one branch (epv_set_tree with n_nodes = 2 and epv_set_model first):

@@ -67,6 +67,7 @@ enum { ORC_REDUCE_SEQ = 0, ORC_REDUCE_TREE = 1 };
  *            segment length.  The parallel rung and the GPU use this one.
  * Segments that keep their state use forward rejection in both (as Nielsen's routine does). */
 enum { ORC_SAMPLER_FORWARD = 0, ORC_SAMPLER_NIELSEN = 1 };
+enum { ORC_PROPOSAL_REFERENCE = 0, ORC_PROPOSAL_TELESCOPED = 1 };
 
 typedef struct {
   uint8_t init;
@@ -109,6 +110,8 @@ typedef struct orc_state {
   int n_thr_scr;
   /* counters */
   uint64_t n_overflow, n_trials, n_draws, n_segments;
+  int proposal_mode;       /* ORC_PROPOSAL_* */
+  double max_qdiff;        /* max |proposal_prob(old) - proposal_prob(new)| seen (reference arithmetic) */
 } orc_state;
 
 static double libm_exp(double x) { return exp(x); }
@@ -362,14 +365,15 @@ static int downward_sampling(orc_state *st, size_t site, orc_scratch *sc, orc_rn
       const double p0 = PT0 * nxt0 / (prev ? s->p1[i] : s->p0[i]);
       const double u = rng_segment_uniform(g, (uint32_t)node, (uint32_t)i);
       const int sampled = (u > p0);
-      log_prob += (sampled == 0) ? st->flog(p0) : st->flog(1.0 - p0);
+      const int ref_q = st->proposal_mode == ORC_PROPOSAL_REFERENCE;
+      if (ref_q) log_prob += (sampled == 0) ? st->flog(p0) : st->flog(1.0 - p0);
 #ifndef _OPENMP
       ++st->n_segments;
 #endif
       if (!overflow)
         overflow = forward_rejection(st, sc, g, (uint32_t)node, (uint32_t)i, r0, r1, prev,
                                      sampled, s->len[i], time_passed, pp);
-      log_prob -= st->flog(get_trans_prob(st, r0, r1, s->len[i], prev, sampled));
+      if (ref_q) log_prob -= st->flog(get_trans_prob(st, r0, r1, s->len[i], prev, sampled));
       time_passed += s->len[i];
       prev = sampled;
     }
@@ -479,8 +483,25 @@ static int mh_site(orc_state *st, size_t site, uint32_t sweep, orc_scratch *sc) 
   double llh_m = st->tri_llh[site];
   double llh_r = st->tri_llh[site + 1];
 
-  const double orig_proposal = proposal_prob(st, site, sc);
-  double llr = orig_proposal - proposal_log_prob;
+  /* q(old)/q(new), SingleSiteSampler.cpp:503-507.  With SAMPLE_ROOT false (hard-wired, :441) the
+   * two log-probabilities are the SAME number in exact arithmetic: per segment the reference
+   * accumulates log P(end | start, data) - log PT(start -> end) = log(p[k+1][end] / p[k][start]),
+   * which telescopes along a branch to log(q[end] / p[0][start]) and over the tree (q of a node is
+   * the product of its children's p[0]; a leaf's q is 1 at the observed state) to
+   * -log prod_{children c of the root} p_c[0][root state]: the normalising constant of the
+   * proposal, which depends on the neighbours and the leaf data but not on the path.  What the
+   * reference evaluates is therefore rounding noise (max_qdiff records it, ~1e-15).
+   * ORC_PROPOSAL_REFERENCE keeps that arithmetic; ORC_PROPOSAL_TELESCOPED uses the exact 0. */
+  double llr = 0.0;
+  if (st->proposal_mode == ORC_PROPOSAL_REFERENCE) {
+    const double orig_proposal = proposal_prob(st, site, sc);
+    llr = orig_proposal - proposal_log_prob;
+    const double a = fabs(llr);
+#ifdef _OPENMP
+#pragma omp critical(orc_qdiff)
+#endif
+    if (a > st->max_qdiff) st->max_qdiff = a;
+  }
   const double llh_l_orig = llh_l, llh_r_orig = llh_r;
   if (!overflow) {
     if (st->g0 + site > 1) llh_l = site_triple_llh(st, site - 1, sc->prop, 1);
@@ -593,9 +614,13 @@ ORC_API void orc_set_modes(orc_state *st, int rng_mode, int math_mode, int sched
   /* default pairing: the reference-schedule rung keeps the reference's forward rejection,
    * the parallel (Philox) rung uses the Nielsen sampler the GPU implements */
   st->sampler_mode = rng_mode == ORC_RNG_PHILOX ? ORC_SAMPLER_NIELSEN : ORC_SAMPLER_FORWARD;
+  /* ... and the exact (telescoped) proposal ratio; the reference rung keeps the reference's sums */
+  st->proposal_mode = rng_mode == ORC_RNG_PHILOX ? ORC_PROPOSAL_TELESCOPED : ORC_PROPOSAL_REFERENCE;
   set_math(st);
 }
 ORC_API void orc_set_sampler(orc_state *st, int sampler_mode) { st->sampler_mode = sampler_mode; }
+ORC_API void orc_set_proposal_mode(orc_state *st, int mode) { st->proposal_mode = mode; }
+ORC_API double orc_get_max_qdiff(const orc_state *st) { return st->max_qdiff; }
 ORC_API void orc_seed_mt(orc_state *st, uint64_t seed) { orc_mt_seed(&st->mt, (uint32_t)seed); }
 ORC_API void orc_seed_philox(orc_state *st, uint64_t seed) { st->seed = seed; }
 ORC_API void orc_set_model(orc_state *st, const double *rates, const double *T) {

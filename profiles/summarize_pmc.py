@@ -17,10 +17,13 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_load  # noqa: E402
+
 
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
+    for r in pmc_load.rows(path):
         if r["Counter_Name"] == counter:
             name = r["Kernel_Name"].split("(")[0]
             name = name[5:] if name.startswith("void ") else name   # templates: "void k<false>"

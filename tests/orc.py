@@ -54,6 +54,10 @@ def orc_lib():
         L.orc_suffstats.argtypes = [C.c_void_p, dp, dp]
         L.orc_suffstats_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, dp, dp]
         L.orc_suffstats_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, dp]
+        L.orc_set_proposal_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_sampler.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_max_qdiff.argtypes = [C.c_void_p]
+        L.orc_get_max_qdiff.restype = C.c_double
         L.orc_set_shard.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.orc_sweep_phase.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_uint64] * 4
         L.orc_sweep_phase.restype = C.c_uint64
@@ -224,6 +228,17 @@ class Oracle(_Engine):
     def seed(self, seed):
         self.L.orc_seed_mt(self.h, seed)
         self.L.orc_seed_philox(self.h, seed)
+
+    def set_proposal_mode(self, reference):
+        """True: q(old)/q(new) by the reference's sums; False: the exact (telescoped) 0"""
+        self.L.orc_set_proposal_mode(self.h, 0 if reference else 1)
+
+    def set_sampler(self, forward):
+        """True: forward rejection for every segment; False: Nielsen for state changes"""
+        self.L.orc_set_sampler(self.h, 0 if forward else 1)
+
+    def max_qdiff(self):
+        return float(self.L.orc_get_max_qdiff(self.h))
 
     def reset(self):
         self.L.orc_reset(self.h)
