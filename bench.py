@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--sites", type=int, default=N_SITES, help="sites per GPU")
     ap.add_argument("--config", default="tree", choices=["tree", "pair", "bal16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-leg", action="store_true",
+                    help="skip the extra steps in reference-arithmetic mode (profiling runs)")
     ap.add_argument("--shards-per-gpu", type=int, default=2,
                     help="contexts per GPU (epievo_amd.parallel.LocalGroup): their dependent kernels "
                          "overlap; results are bit-identical to 1")
@@ -226,16 +228,18 @@ def main():
     # the same steps with the proposal ratio q(old)/q(new) evaluated by the reference's sums
     # (EPV_OPT_REFERENCE_PROPOSAL_RATIO) instead of the exact 0 they amount to: reported beside
     # the headline so that the cost of that arithmetic -- which changes no path -- is on record
-    ss.dev.set_options(reference_proposal_ratio=True)
-    k_ref = max(1, min(2, args.steps))
-    step(args.warmup + args.steps)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(k_ref):
-        step(args.warmup + args.steps + 1 + i)
-    barrier()
-    el_ref = rank_max(time.perf_counter() - t0)
-    ss.dev.set_options()
+    k_ref, el_ref = 0, 0.0
+    if not args.no_reference_leg:
+        ss.dev.set_options(reference_proposal_ratio=True)
+        k_ref = max(1, min(2, args.steps))
+        step(args.warmup + args.steps)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(k_ref):
+            step(args.warmup + args.steps + 1 + i)
+        barrier()
+        el_ref = rank_max(time.perf_counter() - t0)
+        ss.dev.set_options()
 
     B = tree.n_nodes - 1
     owned_total = n_global - 2
@@ -304,11 +308,12 @@ def main():
         }
         out["config"]["proposal_ratio"] = ("exact (q(old)/q(new) = 1 when the root state is kept: "
                                            "DESIGN.md section 4.1); same paths as the reference's sums")
-        out["reference_proposal_arithmetic"] = {
-            "value": float(k_ref) * (BURN_IN + BATCH) * owned_total * B / el_ref, "unit": "site-branch resamples/s",
-            "ms_per_step": el_ref / k_ref * 1e3, "steps": k_ref,
-            "note": "EPV_OPT_REFERENCE_PROPOSAL_RATIO: the two log-probability sums of "
-                    "SingleSiteSampler.cpp:180-339 evaluated as the reference does"}
+        if k_ref:
+          out["reference_proposal_arithmetic"] = {
+              "value": float(k_ref) * (BURN_IN + BATCH) * owned_total * B / el_ref, "unit": "site-branch resamples/s",
+              "ms_per_step": el_ref / k_ref * 1e3, "steps": k_ref,
+              "note": "EPV_OPT_REFERENCE_PROPOSAL_RATIO: the two log-probability sums of "
+                      "SingleSiteSampler.cpp:180-339 evaluated as the reference does"}
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(model, tree, fp_own)
         sys.stdout.flush()

@@ -55,6 +55,15 @@ struct epv_ctx {
   bool mh_gpool = false;        // record pool of the propose kernel in global memory (large trees)
   double *d_gpool = nullptr;
   uint64_t gpool_cap = 0;       // doubles allocated
+  // second-generation proposal kernel (epv_propose2.h)
+  bool use_p2 = true;            // EPV_PROPOSE_V1=1 falls back to the first kernel (A/B runs)
+  uint32_t p2_pool = 0, p2_list_cap = 0;   // LDS: doubles per wave; global slab: rows per lane + heavy records
+  bool p2_gpool = false;
+  size_t p2_lds = 0;
+  double *d_gpool2 = nullptr;
+  uint64_t gpool2_cap = 0;
+  double *d_segtab = nullptr;    // [B][4][6] single-segment matrices, refreshed by epv_reset
+  uint32_t phase_parity = 0;     // accept lists are double-buffered by phase parity
   uint32_t tasks_per_wave = 32;  // epv_mh_jumps_kernel: lanes of a wave that own a task
   double kbar = 0.0;  // mean jumps per (site, branch) of the uploaded paths
   size_t mh_lds = 0;
@@ -99,7 +108,7 @@ struct DevTmp {
 
 void free_paths(epv_ctx *c) {
   dfree(c->S.meta); dfree(c->S.jumps); dfree(c->S.sel); dfree(c->S.tri);
-  dfree(c->S.prop_llr); dfree(c->S.prop_flag); dfree(c->S.prop_states); dfree(c->S.tasks);
+  dfree(c->S.prop_llr); dfree(c->S.prop_flag); dfree(c->S.prop_states); dfree(c->S.tasks); dfree(c->S.alist);
   dfree(c->d_partial[0]); dfree(c->d_partial[1]);
   c->partial_cap[0] = c->partial_cap[1] = 0;
   c->have_paths = c->have_reset = false;
@@ -161,6 +170,60 @@ int plan_mh(epv_ctx *c) {
 
 // the two ping-pong buffers of the canonical tree reduction, sized in DOUBLES for the launch
 // that uses them: level 0 holds one row per block, level 1 one row per 256 blocks
+// launch shape of epv_mh_propose2_kernel: per wave the constants, the matrix table, the node
+// table and a pool of doubles shared by the Felsenstein records (2 doubles) and the heavy-segment
+// records (8 doubles).  The pool covers the typical demand of 64 lanes with a margin (a wave that
+// needs more runs in rounds) and always one lane's worst case.
+double p2_margin() {
+  if (const char *e = std::getenv("EPV_P2_MARGIN")) { const double v = std::atof(e); if (v >= 1.0 && v <= 4.0) return v; }
+  return 1.25;
+}
+int plan_p2(epv_ctx *c) {
+  const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
+  const size_t fixed = const_lds_bytes(N) + (size_t)B * 4u * 6u * 8u + ((((size_t)N * 64u + 1u) / 2u + 1u) & ~(size_t)1u) * 8u +
+                       (3u * (size_t)B * 64u + 15u) / 16u * 16u;   // constants, matrix table, node table, meta cache
+  // one lane's worst case: every branch with 2C+1 segments (records K+1, heavy K)
+  const uint64_t worst_rec = (uint64_t)B * (2u * C + 2u), worst_heavy = (uint64_t)B * (2u * C + 1u);
+  const uint64_t worst_dbl = 2u * worst_rec + 8u * worst_heavy;
+  // typical: K = 1 + Poisson(2 kbar) segments per branch; heavy segments E[K; K >= 2]
+  const double lam = 2.0 * c->kbar;
+  const double heavy_per_branch = (1.0 + lam) - std::exp(-lam);
+  uint32_t n_internal = 0;
+  for (uint32_t node = 1; node < N; ++node) n_internal += c->subtree[node] != 1u;
+  const double rec_per_lane = B * (1.0 + lam) + n_internal;     // K per branch, +1 for an internal node's q
+  const uint64_t typical_dbl = (uint64_t)(64.0 * (2.0 * rec_per_lane + 8.0 * B * heavy_per_branch) * p2_margin()) + 64u;
+  const uint64_t max_fit = fixed + 64u < 160u * 1024u ? (160u * 1024u - fixed) / 8u : 0u;
+  const uint64_t want = std::max(worst_dbl, typical_dbl);
+  const bool lds_ok = want <= max_fit && (fixed + want * 8u) * 8u <= 160u * 1024u;   // >= 8 waves per CU
+  const bool use_lds = std::getenv("EPV_FORCE_GLOBAL_POOL") ? false
+                       : std::getenv("EPV_FORCE_LDS_POOL") ? want <= max_fit : lds_ok;
+  if (fixed > 150u * 1024u) return fail(c, EPV_ERR_ARG, "tree too large for the 160 KiB LDS node table");
+  if (use_lds) {
+    c->p2_gpool = false;
+    c->p2_pool = (uint32_t)want;
+    c->p2_list_cap = 0;
+    c->p2_lds = fixed + (size_t)want * 8u;
+    return EPV_OK;
+  }
+  // global slab per wave: worst_rec rows of 64 interleaved records + a heavy list for the wave
+  const uint64_t rows = worst_rec;
+  const uint64_t list_cap = std::max<uint64_t>(worst_heavy, (uint64_t)(64.0 * B * heavy_per_branch * 2.0) + 64u);
+  const uint64_t blocks = (c->S.phase_cap + 63u) / 64u;
+  const uint64_t need = blocks * (rows * 128u + list_cap * 8u);
+  if (need > c->gpool2_cap) {
+    dfree(c->d_gpool2);
+    c->gpool2_cap = 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc(&c->d_gpool2, need * sizeof(double)));
+    c->gpool2_cap = need;
+  }
+  c->p2_gpool = true;
+  c->p2_pool = (uint32_t)rows;
+  c->p2_list_cap = (uint32_t)list_cap;
+  c->p2_lds = fixed;
+  return EPV_OK;
+}
+
 int ensure_partial_doubles(epv_ctx *c, uint64_t need0, uint64_t need1) {
   if (c->partial_cap[0] >= need0 && c->partial_cap[1] >= need1) return EPV_OK;
   need0 = std::max(need0, c->partial_cap[0]);
@@ -249,8 +312,21 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     ++c->ev_used;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
   }
-  {
-    const bool refq = c->S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO;
+  const bool refq = c->S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO;
+  const bool p2 = c->use_p2 && !refq;   // the reference-arithmetic mode keeps the first kernel
+  uint32_t list_mode = 0;
+  if (p2) {
+    list_mode = 1u + (c->phase_parity & 1u);
+    if (c->p2_gpool)
+      hipLaunchKernelGGL(epv_mh_propose2_kernel<true>, dim3((unsigned)blocks), dim3(64), c->p2_lds, c->stream, c->S,
+                         (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
+                         c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, c->d_gpool2, c->d_segtab);
+    else
+      hipLaunchKernelGGL(epv_mh_propose2_kernel<false>, dim3((unsigned)blocks), dim3(64), c->p2_lds, c->stream, c->S,
+                         (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
+                         c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, (double *)nullptr, c->d_segtab);
+    ++c->phase_parity;
+  } else {
     auto kern = c->mh_gpool ? (refq ? epv_mh_propose_kernel<true, true> : epv_mh_propose_kernel<true, false>)
                             : (refq ? epv_mh_propose_kernel<false, true> : epv_mh_propose_kernel<false, false>);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds, c->stream, c->S,
@@ -267,9 +343,19 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
                        c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, 0.0, 0.0, c->d_counters);
   }
-  hipLaunchKernelGGL(epv_mh_accept_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256),
-                     const_lds_bytes(c->S.N), c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
-                     (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->d_counters);
+  if (list_mode) {
+    // the listed sites (proposal differs from the current path) per shard: typically ~30 % of the
+    // colour; the grid covers half of the worst case and strides over the rest
+    const uint64_t per_shard = (threads + EPV_SHARDS - 1u) / EPV_SHARDS;
+    const unsigned ax = (unsigned)std::max<uint64_t>(1u, (per_shard / 2u + 255u) / 256u);
+    hipLaunchKernelGGL(epv_mh_accept_kernel, dim3(ax, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N), c->stream,
+                       c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo,
+                       own_hi, c->d_counters, list_mode);
+  } else {
+    hipLaunchKernelGGL(epv_mh_accept_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256),
+                       const_lds_bytes(c->S.N), c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->d_counters, 0u);
+  }
   if (c->timing) HIP_TRY(c, hipEventRecord(e1, c->stream));
   HIP_TRY(c, hipGetLastError());
   if (c->halo_mode) ++c->phases_used;
@@ -316,6 +402,7 @@ EPV_API epv_ctx *epv_create(int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return nullptr;
   epv_ctx *c = new epv_ctx();
   c->device = device_id;
+  if (const char *e = std::getenv("EPV_PROPOSE_V1")) c->use_p2 = std::atoi(e) == 0;
   if (const char *e = std::getenv("EPV_TASKS_PER_WAVE")) {  // tuning knob
     const int v = std::atoi(e);
     if (v >= 1 && v <= 64) c->tasks_per_wave = (uint32_t)v;
@@ -329,6 +416,10 @@ EPV_API epv_ctx *epv_create(int device_id) {
     return nullptr;
   }
   // the MH kernel asks for more dynamic LDS than the 64 KiB default
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<true, false>),
@@ -346,7 +437,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows);
+  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_segtab);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->stream);
@@ -386,7 +477,7 @@ EPV_API int epv_set_tree(epv_ctx *c, int n_nodes, const uint32_t *parent_ids,
   c->S.blen = c->d_blen;
   c->have_tree = true;
   c->have_reset = false;
-  if (c->have_paths) return plan_mh(c);
+  if (c->have_paths) { int rc = plan_mh(c); return rc ? rc : plan_p2(c); }
   return EPV_OK;
 }
 
@@ -443,6 +534,9 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   // one task region per counter shard, sized for the worst case of the blocks that use it
   c->S.task_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u * B;
   HIP_TRY(c, hipMalloc(&c->S.tasks, c->S.task_cap * EPV_SHARDS * 2u * sizeof(unsigned long long)));
+  // accept list: one region per counter shard, room for every site of the blocks that use it
+  c->S.alist_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u;
+  HIP_TRY(c, hipMalloc(&c->S.alist, c->S.alist_cap * EPV_SHARDS * sizeof(uint32_t)));
   HIP_TRY(c, hipMemsetAsync(c->S.meta, 0, 2u * E, c->stream));
   // staging of the CSR form
   DevTmp<uint8_t> d_init;
@@ -466,7 +560,7 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   c->phases_used = 0;
   c->have_paths = true;
   c->have_reset = false;
-  return plan_mh(c);
+  { int rc = plan_mh(c); return rc ? rc : plan_p2(c); }
 }
 
 static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base);
@@ -530,7 +624,7 @@ EPV_API int epv_set_capacity(epv_ctx *c, uint32_t capacity) {
   c->S.prop_states = ns.release();
   c->S.C = capacity;
   c->S.W = W;
-  return plan_mh(c);
+  { int rc2 = plan_mh(c); return rc2 ? rc2 : plan_p2(c); }
 }
 
 EPV_API int epv_init_paths_indep(epv_ctx *c, uint64_t n_sites, const uint8_t *root_states,
@@ -773,6 +867,10 @@ EPV_API int epv_reset(epv_ctx *c) {
   HIP_TRY(c, hipSetDevice(c->device));
   hipLaunchKernelGGL(epv_reset_kernel, dim3((unsigned)((c->S.n + 255u) / 256u)), dim3(256),
                      const_lds_bytes(c->S.N), c->stream, c->S);
+  // the single-segment matrices of every (branch, neighbour context): model and branch lengths
+  // are fixed until the next reset
+  if (!c->d_segtab) HIP_TRY(c, hipMalloc(&c->d_segtab, (size_t)4095u * 4u * 6u * sizeof(double)));
+  hipLaunchKernelGGL(epv_segtab_kernel, dim3((c->S.B * 4u + 63u) / 64u), dim3(64), 0, c->stream, c->S, c->d_segtab);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_reset = true;

@@ -48,6 +48,9 @@ struct EpvDev {
   uint64_t task_cap;
   uint64_t phase_cap;  // max sites of one colour phase; the hand-over arrays are indexed by
                        // the phase-local thread id (site = s0 + 3*tid) so they are written densely
+  uint32_t *alist;     // [EPV_SHARDS][alist_cap] phase-local ids of the sites whose proposal differs
+                       // from their current path (the accept kernel's work list)
+  uint64_t alist_cap;
   uint32_t W;        // 64-bit words per (site, branch) in prop_states = ceil((2C+1)/64)
   uint32_t flags;    // EPV_OPT_* (epv_set_options)
   const EpvModelConst *model;  // device copy
@@ -69,7 +72,9 @@ struct EpvIndepConst {
 #define EPV_FLAG_FORWARD_REJECTION 2u         /* state-changing segments by forward rejection too */
 
 // counters[] slots
-enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_TASKS2 = 4, EPV_CNT_N = 5 };
+enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_TASKS2 = 4,
+       EPV_CNT_ALIST0 = 5, EPV_CNT_ALIST1 = 6,   // accept-list lengths, double-buffered by phase parity
+       EPV_CNT_N = 7 };
 // Every counter is sharded 64 ways with a 128-byte stride (one device-scope atomic word
 // saturates near 90 ops/us; 5000 waves hitting ONE word would serialise for ~60 us).
 // A block uses shard (blockIdx.x & 63); the host sums the shards.

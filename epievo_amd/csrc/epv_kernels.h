@@ -645,6 +645,8 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
   }
 }
 
+#include "epv_propose2.h"
+
 // =========================================================================
 //  exact forward rejection (EndCondSampling.cpp:466-509) for the dirty (site, branch)
 //  pairs listed by epv_mh_propose_kernel: ONE LANE PER PAIR, so lanes are dense.  The
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
 #endif
 
 #ifndef EPV_JUMPS_WAVES
-#define EPV_JUMPS_WAVES 3   /* waves per SIMD the register allocation aims for (<= 168 VGPRs) */
+#define EPV_JUMPS_WAVES 2   /* waves per SIMD the register allocation aims for: 3 (<= 168 VGPRs) spills 26 registers, 2 is as fast (tools/ab_bench.py) */
 #endif
 __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
                                                            uint32_t seed_hi, uint32_t sweep,
@@ -868,12 +870,12 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
 // 1302 blocks of a 1e6-site phase then fit the 1536 slots in ONE round (at the natural 92
 // VGPRs there are 1280 slots and 22 blocks run alone in a second round: +15 us)
 #ifndef EPV_ACCEPT_WAVES
-#define EPV_ACCEPT_WAVES 6
+#define EPV_ACCEPT_WAVES 4
 #endif
 __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
     uint64_t first, uint64_t last, uint64_t own_first, uint64_t own_last,
-    unsigned long long *counters) {
+    unsigned long long *counters, uint32_t list_mode) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   __shared__ double s_accd[8 * 256];
   __shared__ uint32_t s_accj[8 * 256];
@@ -884,10 +886,24 @@ __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
   A.d = s_accd + threadIdx.x; A.j = s_accj + threadIdx.x; A.stride = 256u;
   const uint64_t gfirst = S.g0 + first;
   const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
-  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // list_mode 0: one lane per site of the colour (grid x covers them).  list_mode 1 / 2: the
+  // sites epv_mh_propose2_kernel listed (proposal differs from the current path), parity
+  // list_mode - 1, one shard of the list per grid row, grid-stride over its entries.
+  const uint32_t shard_row = blockIdx.y;
+  unsigned long long n_list = 0ull;
+  if (list_mode) n_list = counters[EPV_CNT_IDX(list_mode == 2u ? EPV_CNT_ALIST1 : EPV_CNT_ALIST0, shard_row)];
+  const uint64_t step = list_mode ? (uint64_t)gridDim.x * blockDim.x : ~0ull;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; list_mode ? base < n_list : base == (uint64_t)blockIdx.x * blockDim.x;
+       base += step) {
+  uint64_t tid = base + threadIdx.x;
+  bool have = true;
+  if (list_mode) {
+    have = tid < n_list;
+    tid = have ? S.alist[(uint64_t)shard_row * S.alist_cap + tid] : 0u;
+  }
   const uint64_t site = s0 + 3u * tid;
   bool accepted = false, overflowed = false;
-  if (site <= last) {
+  if (have && site <= last) {
     const uint32_t selL = S.sel[site - 1], selM = S.sel[site], selR = S.sel[site + 1];
     const uint32_t gsite = (uint32_t)(S.g0 + site);
     const bool ovf = S.prop_flag[tid] != 0;
@@ -928,19 +944,22 @@ __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
   }
   const unsigned long long am = __ballot(accepted), om = __ballot(overflowed);
   if (lane == 0) {
-    const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+    const uint32_t shard = (blockIdx.x + blockIdx.y) & (EPV_SHARDS - 1u);
     if (am) atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_ACCEPT, shard)], (unsigned long long)__popcll(am));
     if (om) atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_OVERFLOW, shard)], (unsigned long long)__popcll(om));
   }
+  }
   // the task lists of this phase have been consumed (stream order): fold their lengths
-  // into the running total and clear them for the next propose kernel
-  if (blockIdx.x == 0 && threadIdx.x < EPV_SHARDS) {
+  // into the running total and clear them for the next propose kernel; the accept list of the
+  // OTHER parity was consumed by the previous phase's accept kernel and is filled next
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < EPV_SHARDS) {
     const unsigned long long packed = counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)];
     const unsigned long long packed2 = counters[EPV_CNT_IDX(EPV_CNT_TASKS2, threadIdx.x)];
     counters[EPV_CNT_IDX(EPV_CNT_COOP, threadIdx.x)] +=
         (packed & 0xffffffffull) + (packed >> 32) + (packed2 & 0xffffffffull) + (packed2 >> 32);
     counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)] = 0ull;
     counters[EPV_CNT_IDX(EPV_CNT_TASKS2, threadIdx.x)] = 0ull;
+    if (list_mode) counters[EPV_CNT_IDX(list_mode == 2u ? EPV_CNT_ALIST0 : EPV_CNT_ALIST1, threadIdx.x)] = 0ull;
   }
 }
 
@@ -1260,7 +1279,16 @@ __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t fi
   // block0: first 256-site block to process (partial[] is relative to it)
   const uint64_t site = (block0 + blockIdx.x) * blockDim.x + threadIdx.x;
   const bool on = site >= first && site <= last && site >= 1 && site + 1 < S.n;
+#ifdef EPV_SUFFSTAT_LDS
+  // per-context sums in LDS columns (one per thread): a runtime-indexed update costs ~6
+  // instructions instead of the ~40 of the register select chain
+  __shared__ double s_accd[8 * 256];
+  __shared__ uint32_t s_accj[8 * 256];
+  AccLds A;
+  A.d = s_accd + threadIdx.x; A.j = s_accj + threadIdx.x; A.stride = 256u;
+#else
   Acc8 A;
+#endif
   acc_clear(A);
   if (on) {
     const uint32_t sl = S.sel[site - 1], sm = S.sel[site], sr = S.sel[site + 1];
@@ -1270,7 +1298,7 @@ __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t fi
   }
   double v[16];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { v[c] = (double)A.j[c]; v[8 + c] = A.d[c]; }
+  for (int c = 0; c < 8; ++c) { v[c] = (double)acc_j(A, c); v[8 + c] = acc_d(A, c); }
   int idx;
   const double tot = wave_tree_sum16(v, lane, idx);
   if (lane < 16) s_part[wave][idx] = tot;

@@ -1,0 +1,387 @@
+#ifndef EPV_PROPOSE2_H
+#define EPV_PROPOSE2_H
+// epv_propose2.h -- the proposal kernel of a colour phase, second generation (included by
+// epv_kernels.h).  Same contract as epv_mh_propose_kernel<., false> -- pruning
+// (SingleSiteSampler.cpp:116-157) and downward sampling of the segment end states (:180-255) of
+// one site per lane, bit for bit the numbers of the oracle's parallel rung -- reorganised
+// around what the lanes of a wave have in common:
+//
+//  * ~90 % of the (site, branch) pairs on a short tree have ONE segment (no neighbour jump on
+//    that branch).  Its transition matrix depends only on (branch, left state, right state):
+//    epv_segtab_kernel evaluates the 4 B matrices once per reset (the very expressions of the
+//    per-segment code, so the bits are the same) and the lanes read them from LDS -- no exp,
+//    no division.
+//  * the other ("heavy") branches drove the cost of the first kernel: a wave iterated
+//    max_lanes(K) times over exp + divisions although the average lane has 1.1 segments
+//    (lane utilisation 44 %, profiles/r02b_pmc_valu_tree.csv).  Here the lanes only LIST their
+//    heavy segments (length, context, Philox address) in LDS; the wave then evaluates the list
+//    densely, one segment per lane -- matrices, no-jump bounds and the segment's Philox block,
+//    none of which depends on the recursion state -- and the two recursions (Felsenstein
+//    partials upwards, end states downwards) read finished 64-byte records: their divergent
+//    loops are a handful of FMAs (and one division) per iteration.
+//  * a proposal that EQUALS the current path on every branch (no jumps on either, same states:
+//    ~70 % of the sites of tree.nwk) is accepted with probability one and changes nothing --
+//    the likelihoods it would recompute are the cached ones.  Such a site is counted here and
+//    never reaches the accept kernel; all other sites are appended to a compact list that
+//    epv_mh_accept_kernel walks with dense lanes.
+//
+// LDS per wave: constants, the matrix table, the node table regA[N][64] (record offset of the
+// branch above the node | proposal end state << 31) and a pool of doubles holding, for the
+// lanes that run in this round, their Felsenstein records {p0, p1} (K per branch, +1 for the
+// q of an internal node) followed by the wave's heavy-segment records.  GPOOL = true keeps the
+// pool in a per-wave slab of global memory (large trees), records interleaved by lane.
+
+struct EpvSegRec {      // one segment, everything the recursions need
+  double P00, P11;      // continuous_time_trans_prob_mat (pruning form: h = 1 / exp(len (r0 + r1)))
+  double PT00, PT10;    // get_trans_prob(len, prev, 0) for prev = 0, 1 (h = exp(-len (r0 + r1)))
+  double nb0, nb1;      // no-jump bounds of trial 1 for a segment that waits in state 0 / 1
+  double u_end, u_first;  // the segment's Philox block: end-state uniform, trial 1's first draw
+};
+#define EPV_SEGTAB_DBL 6u   /* table entry = the first six fields */
+
+__device__ __forceinline__ void epv_seg_matrices(double len, double r0, double r1, double out[6]) {
+  const double denom = r0 + r1;
+  const double h = 1.0 / epv_exp(len * (r0 + r1));     // ContinuousTimeMarkovModel.cpp:143-161
+  out[0] = (r0 * h + r1) / denom;
+  out[1] = (r0 + r1 * h) / denom;
+  const double h2 = epv_exp(-len * (r0 + r1));         // :116-125, shared by both start states
+  out[2] = gtp(r0, r1, h2, denom, 0u, 0u);
+  out[3] = gtp(r0, r1, h2, denom, 1u, 0u);
+  out[4] = nojump_bound(len * r0);
+  out[5] = nojump_bound(len * r1);
+}
+
+// tab[(b * 4 + 2 * left_state + right_state) * 6 ..]: the single segment of branch b (length =
+// the branch length) in each of the four neighbour contexts
+__global__ void epv_segtab_kernel(EpvDev S, double *tab) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= S.B * 4u) return;
+  const uint32_t b = t >> 2, li = (t >> 1) & 1u, ri = t & 1u;
+  const double *rates = reinterpret_cast<const double *>(S.model);
+  const uint32_t trip0 = 4u * li + ri;
+  const double len = S.blen[b + 1u] - 0.0;
+  double m[6];
+  epv_seg_matrices(len, rates[trip0], rates[trip0 | 2u], m);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) tab[(size_t)t * EPV_SEGTAB_DBL + i] = m[i];
+}
+
+// Append the dirty (site, branch) pairs of the last <= 64 branches to the task lists of this
+// block's shard -- a WAVE-WIDE operation (lanes without dirty bits pass zeros).  Four buckets by
+// segment count so that the waves of the jumps kernel, which take consecutive tasks, hold lanes
+// with similar loop counts: a shard has two regions, each filled from BOTH ends (counts packed
+// lo/hi in one word) -- region 0: K = 1 from the front, K = 2 from the back; region 1: K = 3
+// from the front, K >= 4 from the back.  One atomic per wave and region reserves the slots.
+__device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long long *counters,
+                                                unsigned long long dirty, unsigned long long multi,
+                                                unsigned long long deep, uint32_t b, uint64_t site, int lane) {
+  const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+#pragma unroll
+  for (uint32_t reg = 0; reg < 2u; ++reg) {
+    const unsigned long long mine_reg = reg ? (dirty & deep) : (dirty & ~deep);
+    const uint32_t mineB = (uint32_t)__popcll(mine_reg & multi);
+    const uint32_t mineA = (uint32_t)__popcll(mine_reg) - mineB;
+    const uint32_t inclA = wave_incl_scan_u32(mineA), inclB = wave_incl_scan_u32(mineB);
+    const uint32_t totalA = __shfl(inclA, 63), totalB = __shfl(inclB, 63);
+    if (totalA | totalB) {
+      unsigned long long base = 0ull;
+      if (lane == 0)
+        base = atomicAdd(&counters[EPV_CNT_IDX(reg ? EPV_CNT_TASKS2 : EPV_CNT_TASKS, shard)],
+                         (unsigned long long)totalA | ((unsigned long long)totalB << 32));
+      const uint32_t baseA = __shfl((uint32_t)base, 0), baseB = __shfl((uint32_t)(base >> 32), 0);
+      unsigned long long *region = S.tasks + ((unsigned long long)shard * 2u + reg) * S.task_cap;
+      unsigned long long slotA = (unsigned long long)baseA + (inclA - mineA);
+      unsigned long long slotB = S.task_cap - 1ull - ((unsigned long long)baseB + (inclB - mineB));
+      unsigned long long d = mine_reg;
+      while (d) {
+        const uint32_t bit = (uint32_t)(__ffsll((long long)d) - 1);
+        d &= d - 1ull;
+        const unsigned long long t = ((unsigned long long)((b & ~63u) + bit) << 40) | site;
+        if ((multi >> bit) & 1ull) region[slotB--] = t;
+        else region[slotA++] = t;
+      }
+    }
+  }
+}
+
+#ifndef EPV_PROPOSE2_WAVES
+#define EPV_PROPOSE2_WAVES 3
+#endif
+
+template <bool GPOOL>
+__global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel(
+    EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first,
+    uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t pool_dbl, uint32_t list_cap,
+    uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab) {
+  // pool_dbl: LDS pool -- doubles per wave; GPOOL -- record ROWS per lane (list_cap heavy records
+  // behind them; unused for the LDS pool, where records and list share pool_dbl)
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
+  const uint32_t tab_dbl = S.B * 4u * EPV_SEGTAB_DBL;
+  const uint32_t regA_dbl = ((S.N * 64u + 1u) / 2u + 1u) & ~1u;
+  const uint32_t mc_dbl = (3u * S.B * 64u + 15u) / 16u * 2u;     // meta bytes of the three columns
+  double *s_const = s_mem;
+  double *s_tab = s_mem + const_dbl;
+  uint32_t *regA = reinterpret_cast<uint32_t *>(s_mem + const_dbl + tab_dbl);
+  // s_meta[(which * B + b) * 64 + lane], which = 0 left, 1 right, 2 this site: fetched ONCE, in one
+  // batch of independent loads; the four passes below then read LDS instead of paying a global
+  // round trip per branch (the kernel is bound by memory latency, not by issue)
+  uint8_t *s_meta = reinterpret_cast<uint8_t *>(s_mem + const_dbl + tab_dbl + regA_dbl);
+  const int lane = epv_lane();
+  // GPOOL: rows of 64 interleaved records (row r of lane l at (r * 64 + l) * 2 doubles), then
+  // the flat heavy list; LDS: records packed by a wave prefix sum, the heavy list behind them
+  double *pool = GPOOL ? gpool + (size_t)blockIdx.x * ((size_t)pool_dbl * 128u + (size_t)list_cap * 8u)
+                       : s_mem + const_dbl + tab_dbl + regA_dbl + mc_dbl;
+  for (uint32_t i = threadIdx.x; i < tab_dbl; i += blockDim.x) s_tab[i] = segtab[i];
+  stage_constants(S, s_const);
+  const double *s_rates = s_const;
+  const double *s_blen = s_const + 20;
+
+  const uint64_t gfirst = S.g0 + first;
+  const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t site = s0 + 3u * tid;
+  const bool valid = site <= last;
+  const uint64_t n = S.n;
+  const uint32_t B = S.B;
+  const uint32_t gsite = (uint32_t)(S.g0 + site);
+  const uint32_t gsite_lane0 = gsite - 3u * (uint32_t)lane;
+
+  uint32_t selL = 0, selM = 0, selR = 0;
+  uint32_t need_rec = 0, heavy = 0;
+  if (valid) {
+    selL = S.sel[site - 1]; selM = S.sel[site]; selR = S.sel[site + 1];
+#pragma unroll 4
+    for (uint32_t b = 0; b < B; ++b) {
+      const uint32_t mL = S.meta[meta_idx(S, selL, b, site - 1)];
+      const uint32_t mR = S.meta[meta_idx(S, selR, b, site + 1)];
+      const uint32_t mM = S.meta[meta_idx(S, selM, b, site)];
+      s_meta[(0u * B + b) * 64u + lane] = (uint8_t)mL;
+      s_meta[(1u * B + b) * 64u + lane] = (uint8_t)mR;
+      s_meta[(2u * B + b) * 64u + lane] = (uint8_t)mM;
+      const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
+      need_rec += K + (S.subtree[b + 1u] != 1u ? 1u : 0u);
+      if (K >= 2u) heavy += K;
+    }
+  }
+
+  bool pending = valid;
+  while (__any(pending)) {
+    const uint32_t wantR = pending ? need_rec : 0u, wantH = pending ? heavy : 0u;
+    const uint32_t inclR = wave_incl_scan_u32(wantR), inclH = wave_incl_scan_u32(wantH);
+    // non-decreasing in the lane index, so the lanes that run are a prefix of the pending ones
+    const bool run = pending && (GPOOL ? (need_rec <= pool_dbl && inclH <= list_cap)
+                                       : (2u * inclR + 8u * inclH <= pool_dbl));
+    const unsigned long long rmask = __ballot(run);
+    const int hi_lane = rmask ? 63 - __clzll((long long)rmask) : 0;
+    const uint32_t totR = rmask ? __shfl(inclR, hi_lane) : 0u, totH = rmask ? __shfl(inclH, hi_lane) : 0u;
+    constexpr size_t RS = GPOOL ? 128u : 2u;   // doubles between consecutive records of a lane
+    double *my = GPOOL ? pool + (size_t)lane * 2u : pool + (size_t)(inclR - wantR) * 2u;
+    double *list = GPOOL ? pool + (size_t)pool_dbl * 128u : pool + (size_t)totR * 2u;
+    const uint32_t hbase = inclH - wantH;
+
+    // ---- 1. list the heavy segments: forward merge of the neighbours' jumps (Segment.cpp:35-79)
+    if (run && heavy) {
+      uint32_t hcur = hbase;
+      for (uint32_t node = 1u; node < S.N; ++node) {
+        const uint32_t b = node - 1u;
+        const uint32_t cL = s_meta[(0u * B + b) * 64u + lane], cR = s_meta[(1u * B + b) * 64u + lane];
+        const uint32_t K = (cL & 127u) + (cR & 127u) + 1u;
+        if (K < 2u) continue;
+        PathRef L, R;
+        L.j = S.jumps + ((uint64_t)selL * B + b) * S.C * n + (site - 1); L.nj = cL & 127u; L.init = cL >> 7;
+        R.j = S.jumps + ((uint64_t)selR * B + b) * S.C * n + (site + 1); R.nj = cR & 127u; R.init = cR >> 7;
+        uint32_t trip0 = 4u * L.init + R.init, i = 0, j = 0;
+        double seg_start = 0.0;
+        double tl = L.nj ? L.j[0] : EPV_INF, tr = R.nj ? R.j[0] : EPV_INF;
+        for (uint32_t k = 0; k < K; ++k) {
+          const bool last_seg = (k + 1u == K);
+          const bool take_left = tl < tr;
+          const double seg_end = last_seg ? s_blen[node] : (take_left ? tl : tr);
+          double *rec = list + (size_t)(hcur + k) * 8u;
+          rec[0] = seg_end - seg_start;
+          rec[1] = epv_u2d((uint64_t)trip0 | ((uint64_t)lane << 3) | ((uint64_t)node << 9) | ((uint64_t)k << 21));
+          if (!last_seg) {
+            if (take_left) { trip0 ^= 4u; ++i; tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF; }
+            else { trip0 ^= 1u; ++j; tr = j < R.nj ? R.j[(uint64_t)j * n] : EPV_INF; }
+            seg_start = seg_end;
+          }
+        }
+        hcur += K;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- 2. evaluate them densely, one segment per lane
+    for (uint32_t i = (uint32_t)lane; i < totH; i += 64u) {
+      double *rec = list + (size_t)i * 8u;
+      const double len = rec[0];
+      const uint64_t info = epv_d2u(rec[1]);
+      const uint32_t trip0 = (uint32_t)info & 7u, owner = (uint32_t)(info >> 3) & 63u;
+      const uint32_t node = (uint32_t)(info >> 9) & 4095u, k = (uint32_t)(info >> 21);
+      double m[6];
+      epv_seg_matrices(len, s_rates[trip0], s_rates[trip0 | 2u], m);
+      const epv_block2 blk = epv_keyed_block(seed_lo, seed_hi, gsite_lane0 + 3u * owner, sweep, node, k, 0u, 0u);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) rec[q] = m[q];
+      rec[6] = blk.d0;
+      rec[7] = blk.d1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    bool ident = true;
+    if (run) {
+      // ---- 3. pruning, reverse pre-order (SingleSiteSampler.cpp:116-157)
+      uint32_t off = need_rec, hcur = hbase + heavy;
+      for (uint32_t node = S.N - 1u; node >= 1u; --node) {
+        const uint32_t b = node - 1u;
+        const uint32_t mL = s_meta[(0u * B + b) * 64u + lane], mR = s_meta[(1u * B + b) * 64u + lane];
+        const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
+        const uint32_t sub = S.subtree[node];
+        off -= K + (sub != 1u ? 1u : 0u);
+        double n0 = 1.0, n1 = 1.0;
+        if (sub == 1u) {
+          const uint32_t mM = s_meta[(2u * B + b) * 64u + lane];
+          const uint32_t leaf_state = (mM >> 7) ^ (mM & 1u);
+          n0 = leaf_state ? 0.0 : 1.0;
+          n1 = leaf_state ? 1.0 : 0.0;
+        } else {
+          for (uint32_t ch = 1u; ch < sub; ch += S.subtree[node + ch]) {
+            const double *a = my + (size_t)(regA[(node + ch) * 64u + lane] & 0x7fffffffu) * RS;
+            n0 *= a[0];   // p.front() of the child's branch
+            n1 *= a[1];
+          }
+          double *recq = my + (size_t)(off + K) * RS;
+          recq[0] = n0; recq[1] = n1;
+        }
+        regA[node * 64u + lane] = off;
+        if (K == 1u) {
+          const double *t = s_tab + (size_t)(b * 4u + 2u * (mL >> 7) + (mR >> 7)) * EPV_SEGTAB_DBL;
+          const double P00 = t[0], P11 = t[1];
+          const double P01 = 1.0 - P00, P10 = 1.0 - P11;
+          double *rec = my + (size_t)off * RS;
+          rec[0] = P00 * n0 + P01 * n1;
+          rec[1] = P10 * n0 + P11 * n1;
+        } else {
+          hcur -= K;
+          for (uint32_t kk = K; kk-- > 0u;) {
+            const double *hr = list + (size_t)(hcur + kk) * 8u;
+            const double P00 = hr[0], P11 = hr[1];
+            const double P01 = 1.0 - P00, P10 = 1.0 - P11;
+            const double a = P00 * n0 + P01 * n1;
+            const double c = P10 * n0 + P11 * n1;
+            double *rec = my + (size_t)(off + kk) * RS;
+            rec[0] = a; rec[1] = c;
+            n0 = a; n1 = c;
+          }
+        }
+      }
+    }
+
+    // ---- 4. downward sampling of the segment END STATES (:180-255); the jump times are drawn
+    //         by epv_mh_jumps_kernel for the dirty branches only (see epv_kernels.h).  The node
+    //         loop is wave-uniform: the task flush inside it is a wave-wide operation.
+    unsigned long long dirty = 0ull, multi = 0ull, deep = 0ull;
+    const uint32_t root_state = run ? (uint32_t)(s_meta[(2u * B) * 64u + lane] >> 7) : 0u;
+    uint32_t hcur = hbase;
+    for (uint32_t node = 1u; node < S.N; ++node) {
+      const uint32_t b = node - 1u;
+      if (run) {
+        const uint32_t mL = s_meta[(0u * B + b) * 64u + lane], mR = s_meta[(1u * B + b) * 64u + lane];
+        const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
+        const uint32_t off = regA[node * 64u + lane];
+        const uint32_t par = S.parent[node];
+        const uint32_t start_state = (par == 0u) ? root_state : (regA[par * 64u + lane] >> 31);
+        const bool leaf = S.subtree[node] == 1u;
+        const uint32_t mM = s_meta[(2u * B + b) * 64u + lane];
+        uint32_t prev = start_state;
+        bool clean = true;
+        unsigned long long word = 0ull;
+        uint64_t *states = S.prop_states + ((uint64_t)b * S.phase_cap + tid) * S.W;
+        double pk0 = my[(size_t)off * RS], pk1 = my[(size_t)off * RS + 1u];
+        for (uint32_t k = 0; k < K; ++k) {
+          const bool last_seg = (k + 1u == K);
+          double nxt0, nxt1;
+          if (last_seg && leaf) {          // q of a leaf: the observed state
+            const uint32_t leaf_state = (mM >> 7) ^ (mM & 1u);
+            nxt0 = leaf_state ? 0.0 : 1.0;
+            nxt1 = leaf_state ? 1.0 : 0.0;
+          } else {
+            nxt0 = my[(size_t)(off + k + 1u) * RS];      // p[k+1], or the node's q
+            nxt1 = my[(size_t)(off + k + 1u) * RS + 1u];
+          }
+          double PT0, nb, u_end, u_first;
+          if (K == 1u) {
+            const double *t = s_tab + (size_t)(b * 4u + 2u * (mL >> 7) + (mR >> 7)) * EPV_SEGTAB_DBL;
+            PT0 = prev ? t[3] : t[2];
+            nb = prev ? t[5] : t[4];
+            const epv_block2 blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, 0u, 0u, 0u);
+            u_end = blk.d0; u_first = blk.d1;
+          } else {
+            const double *hr = list + (size_t)(hcur + k) * 8u;
+            PT0 = prev ? hr[3] : hr[2];
+            nb = prev ? hr[5] : hr[4];
+            u_end = hr[6]; u_first = hr[7];
+          }
+          const double p0 = PT0 * nxt0 / (prev ? pk1 : pk0);
+          const uint32_t sampled = (u_end > p0) ? 1u : 0u;
+          // trial 1's first draw is the other half of the same Philox block
+          clean = clean && (sampled == prev) && (1.0 - u_first < nb);
+          word |= (unsigned long long)sampled << (k & 63u);
+          if ((k & 63u) == 63u) { states[k >> 6] = word; word = 0ull; }
+          prev = sampled;
+          pk0 = nxt0; pk1 = nxt1;
+        }
+        if (K >= 2u) hcur += K;
+        if ((K & 63u) && !clean) states[(K - 1u) >> 6] = word;   // only a dirty branch is read back
+        regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children
+        // same as the current path?  (no jumps on either, same start state)
+        ident = ident && clean && mM == (start_state << 7);
+        if (!clean) {
+          dirty |= 1ull << (b & 63u);
+          if (K == 2u || K >= 4u) multi |= 1ull << (b & 63u);   // four buckets by segment count
+          if (K >= 3u) deep |= 1ull << (b & 63u);
+        }
+      }
+      if ((b & 63u) == 63u || node + 1u == S.N) {
+        epv_flush_tasks(S, counters, dirty, multi, deep, b, site, lane);
+        dirty = multi = deep = 0ull;
+      }
+    }
+
+    // ---- 5. hand-over.  A proposal equal to the current path is accepted with probability one
+    //         and changes neither the paths nor the cached likelihoods: count it and be done.
+    //         Everything else: start states of the proposal's branches into the other buffer,
+    //         and the site onto the accept list of this block's shard.
+    const bool to_list = run && !ident;
+    if (to_list) {
+      for (uint32_t node = 1u; node < S.N; ++node) {
+        const uint32_t par = S.parent[node];
+        const uint32_t st = (par == 0u) ? root_state : (regA[par * 64u + lane] >> 31);
+        S.meta[meta_idx(S, selM ^ 1u, node - 1u, site)] = (uint8_t)(st << 7);
+      }
+      S.prop_flag[tid] = 0u;
+    }
+    {
+      const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+      const unsigned long long lm = __ballot(to_list);
+      if (lm) {
+        unsigned long long base = 0ull;
+        if (lane == 0)
+          base = atomicAdd(&counters[EPV_CNT_IDX(parity ? EPV_CNT_ALIST1 : EPV_CNT_ALIST0, shard)],
+                           (unsigned long long)__popcll(lm));
+        const uint32_t b0 = __shfl((uint32_t)base, 0);
+        if (to_list)
+          S.alist[(uint64_t)shard * S.alist_cap + b0 + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)tid;
+      }
+      const unsigned long long am = __ballot(run && ident && site >= own_first && site <= own_last);
+      if (am && lane == 0)
+        atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_ACCEPT, shard)], (unsigned long long)__popcll(am));
+    }
+    pending = pending && !run;
+  }
+}
+
+#endif
