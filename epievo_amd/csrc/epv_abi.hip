@@ -64,7 +64,7 @@ struct epv_ctx {
   uint64_t gpool2_cap = 0;
   double *d_segtab = nullptr;    // [B][4][6] single-segment matrices, refreshed by epv_reset
   uint32_t phase_parity = 0;     // accept lists are double-buffered by phase parity
-  uint32_t tasks_per_wave = 32;  // epv_mh_jumps_kernel: lanes of a wave that own a task
+  uint32_t tasks_per_wave = 0;   // epv_mh_jumps_kernel: lanes of a wave that own a task (0 = by workload)
   double kbar = 0.0;  // mean jumps per (site, branch) of the uploaded paths
   size_t mh_lds = 0;
   // counters / timing
@@ -181,7 +181,7 @@ double p2_margin() {
 int plan_p2(epv_ctx *c) {
   const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
   const size_t fixed = const_lds_bytes(N) + (size_t)B * 4u * 6u * 8u + ((((size_t)N * 64u + 1u) / 2u + 1u) & ~(size_t)1u) * 8u +
-                       (3u * (size_t)B * 64u + 15u) / 16u * 16u;   // constants, matrix table, node table, meta cache
+                       (3u * (size_t)B * 64u * sizeof(epv_meta_t) + 15u) / 16u * 16u;   // constants, matrix table, node table, meta cache
   // one lane's worst case: every branch with 2C+1 segments (records K+1, heavy K)
   const uint64_t worst_rec = (uint64_t)B * (2u * C + 2u), worst_heavy = (uint64_t)B * (2u * C + 1u);
   const uint64_t worst_dbl = 2u * worst_rec + 8u * worst_heavy;
@@ -313,7 +313,12 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     HIP_TRY(c, hipEventRecord(e0, c->stream));
   }
   const bool refq = c->S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO;
-  const bool p2 = c->use_p2 && !refq;   // the reference-arithmetic mode keeps the first kernel
+  // the reference-arithmetic mode keeps the first kernel, and so do trees whose record pool does
+  // not fit LDS: with the pool in global memory the second kernel's extra passes over it cost
+  // more than its dense evaluation saves (16-leaf tree: 830 vs 676 us);
+  // EPV_PROPOSE_V2_GLOBAL=1 forces it for A/B runs
+  static const bool p2_global = std::getenv("EPV_PROPOSE_V2_GLOBAL") != nullptr;
+  const bool p2 = c->use_p2 && !refq && (!c->p2_gpool || p2_global);
   uint32_t list_mode = 0;
   if (p2) {
     list_mode = 1u + (c->phase_parity & 1u);
@@ -337,7 +342,14 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     // one lane per dirty (site, branch) pair; the count is only known on the device, so
     // launch a grid that covers the typical case and grid-stride over the rest
     const uint64_t max_tasks = blocks / EPV_SHARDS * 64u * c->S.B + 64u * c->S.B;  // per shard
-    const uint32_t tpw = c->tasks_per_wave;
+    // lanes of a wave that own a task (the others only help in the cooperative search): full
+    // waves when there is work for every SIMD, fewer tasks per wave -- a shorter critical path --
+    // on a small genome (measured: tools/ab_envbench.py EPV_TASKS_PER_WAVE)
+    uint32_t tpw = c->tasks_per_wave;
+    if (tpw == 0) {
+      const double est = (double)threads * c->S.B * std::min(1.0, 0.1 + c->kbar) / 2048.0;
+      tpw = est >= 64.0 ? 64u : est >= 32.0 ? 32u : est >= 16.0 ? 16u : 8u;
+    }
     // a block (4 waves) takes 4*tpw tasks per pass; size the grid for ~1/4 of the worst case
     const uint64_t jb = std::min<uint64_t>((max_tasks / 4u + 4u * tpw - 1u) / (4u * tpw) + 1u, 256u);
     hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
@@ -522,7 +534,7 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   c->S.n_global = global_site_offset + n_sites;
   c->S.C = capacity;
   c->kbar = E ? (double)offsets[E] / (double)E : 0.0;
-  HIP_TRY(c, hipMalloc(&c->S.meta, 2u * E));
+  HIP_TRY(c, hipMalloc(&c->S.meta, 2u * E * sizeof(epv_meta_t)));
   HIP_TRY(c, hipMalloc(&c->S.jumps, 2u * E * capacity * sizeof(double)));
   HIP_TRY(c, hipMalloc(&c->S.sel, n_sites));
   HIP_TRY(c, hipMalloc(&c->S.tri, n_sites * sizeof(double)));
@@ -537,7 +549,7 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   // accept list: one region per counter shard, room for every site of the blocks that use it
   c->S.alist_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u;
   HIP_TRY(c, hipMalloc(&c->S.alist, c->S.alist_cap * EPV_SHARDS * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemsetAsync(c->S.meta, 0, 2u * E, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->S.meta, 0, 2u * E * sizeof(epv_meta_t), c->stream));
   // staging of the CSR form
   DevTmp<uint8_t> d_init;
   DevTmp<uint64_t> d_off;
@@ -597,14 +609,14 @@ EPV_API int epv_set_capacity(epv_ctx *c, uint32_t capacity) {
   if (capacity < c->S.C) {
     // shrinking: every resident path (either buffer: a stale proposal is overwritten before
     // it is read, but keep the test simple) must fit
-    std::vector<uint8_t> meta(2u * E);
-    HIP_TRY(c, hipMemcpyAsync(meta.data(), c->S.meta, 2u * E, hipMemcpyDeviceToHost, c->stream));
+    std::vector<epv_meta_t> meta(2u * E);
+    HIP_TRY(c, hipMemcpyAsync(meta.data(), c->S.meta, 2u * E * sizeof(epv_meta_t), hipMemcpyDeviceToHost, c->stream));
     std::vector<uint8_t> sel(n);
     HIP_TRY(c, hipMemcpyAsync(sel.data(), c->S.sel, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (uint64_t s = 0; s < n; ++s)
       for (uint64_t b = 0; b < B; ++b)
-        if ((meta[((uint64_t)sel[s] * B + b) * n + s] & 127u) > capacity)
+        if ((meta[((uint64_t)sel[s] * B + b) * n + s] & EPV_NJ_MASK) > capacity)
           return fail(c, EPV_ERR_CAPACITY, "a resident path has more jumps than the requested capacity");
   }
   DevTmp<double> nj;
@@ -652,10 +664,11 @@ EPV_API int epv_init_paths_indep(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
     hipLaunchKernelGGL(epv_init_tasks_kernel, dim3((unsigned)((threads + 63u) / 64u)), dim3(64), 0, c->stream,
                        c->S, colour, first, last, d_leaf, c->d_counters);
     const uint64_t per_shard = threads / EPV_SHARDS + 256u;
-    const uint64_t jb = std::min<uint64_t>((per_shard + 4u * c->tasks_per_wave - 1u) / (4u * c->tasks_per_wave), 256u);
+    const uint32_t tpw = c->tasks_per_wave ? c->tasks_per_wave : 32u;
+    const uint64_t jb = std::min<uint64_t>((per_shard + 4u * tpw - 1u) / (4u * tpw), 256u);
     hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
                        c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), EPV_INIT_SWEEP,
-                       c->tasks_per_wave, s0, 0.0, 0.0, c->d_counters);
+                       tpw, s0, 0.0, 0.0, c->d_counters);
     hipLaunchKernelGGL(epv_init_commit_kernel, dim3(blocks), dim3(256), 0, c->stream, c->S, colour, first,
                        last, c->d_counters);
   }
@@ -804,7 +817,7 @@ EPV_API int epv_indep_update_paths(epv_ctx *c, const double *rates, uint64_t see
                        c->d_indep, rates[0], rates[1], colour, first, last, (uint32_t)seed,
                        (uint32_t)(seed >> 32), sweep, c->d_counters);
     const uint64_t max_tasks = blocks / EPV_SHARDS * 64u * c->S.B + 64u * c->S.B;
-    const uint32_t tpw = c->tasks_per_wave;
+    const uint32_t tpw = c->tasks_per_wave ? c->tasks_per_wave : 32u;
     const uint64_t jb = std::min<uint64_t>((max_tasks / 4u + 4u * tpw - 1u) / (4u * tpw) + 1u, 256u);
     hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
                        c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, rates[0],
@@ -1273,7 +1286,7 @@ EPV_API int epv_get_tri_llh(epv_ctx *c, double *out) {
 
 EPV_API uint64_t epv_column_bytes(const epv_ctx *c) {
   if (!c || !c->have_paths) return 0;
-  return (((uint64_t)c->S.B + 7u) & ~7ull) + ((uint64_t)c->S.B * c->S.C + 3u) * 8u;
+  return (((uint64_t)c->S.B * sizeof(epv_meta_t) + 7u) & ~7ull) + ((uint64_t)c->S.B * c->S.C + 3u) * 8u;
 }
 
 EPV_API int epv_get_columns(epv_ctx *c, uint64_t first, uint64_t count, void *packed) {

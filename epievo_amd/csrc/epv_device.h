@@ -1,8 +1,8 @@
 // epv_device.h -- device-side data layout shared by the kernels and the ABI glue.
 //
 // HBM layout (SoA, "jump times packed as SoA for coalesced access"):
-//   meta [2][B][n]     u8   bit7 = Path::init_state, bits0-6 = number of jumps.  Branch-major:
-//                           a wave's loads of one branch are stride-3 bytes (one or two cache
+//   meta [2][B][n]     u16  bit15 = Path::init_state, bits0-14 = number of jumps.  Branch-major:
+//                           a wave's loads of one branch are stride-3 words (a few cache
 //                           lines); the site-major alternative [2][n][B] costs a line per two
 //                           lanes at 30 branches (measured: 2.41 vs 1.63 ms per phase)
 //   jumps[2][B][C][n]  f64  jump k of (buffer, branch, site) at ((buf*B+b)*C+k)*n+site
@@ -19,7 +19,13 @@
 
 #include <stdint.h>
 
-#define EPV_MAX_CAP 127u
+// meta word of a path: bit 15 = Path::init_state, bits 0-14 = number of jumps.  The capacity
+// (jump slots per path) is bounded by the 12-bit segment field of the Philox address: a branch
+// has at most 2 C + 1 <= 4095 segments.
+typedef uint16_t epv_meta_t;
+#define EPV_INIT_SHIFT 15
+#define EPV_NJ_MASK 0x7fffu
+#define EPV_MAX_CAP 2047u
 #define EPV_WAVE 64
 
 struct EpvModelConst {  // staged into LDS by every block
@@ -35,7 +41,7 @@ struct EpvDev {
   uint32_t B;        // branches = n_nodes - 1
   uint32_t C;        // jump capacity per (site, branch)
   uint32_t N;        // nodes
-  uint8_t *meta;
+  epv_meta_t *meta;
   double *jumps;
   uint8_t *sel;
   double *tri;

@@ -97,11 +97,11 @@ struct PathRef {
 __device__ __forceinline__ PathRef path_ref(const EpvDev &S, uint32_t buf, uint32_t b,
                                             uint64_t site) {
   const uint64_t plane = (uint64_t)buf * S.B + b;
-  const uint8_t m = S.meta[meta_idx(S, buf, b, site)];
+  const epv_meta_t m = S.meta[meta_idx(S, buf, b, site)];
   PathRef p;
   p.j = S.jumps + plane * S.C * S.n + site;
-  p.nj = m & 127u;
-  p.init = m >> 7;
+  p.nj = m & EPV_NJ_MASK;
+  p.init = m >> EPV_INIT_SHIFT;
   return p;
 }
 
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
     for (uint32_t b = 0; b < B; ++b) {
       const uint32_t mL = S.meta[meta_idx(S, selL, b, site - 1)];
       const uint32_t mR = S.meta[meta_idx(S, selR, b, site + 1)];
-      need += (mL & 127u) + (mR & 127u) + 2u;  // K segments + 1 record for q
+      need += (mL & EPV_NJ_MASK) + (mR & EPV_NJ_MASK) + 2u;  // K segments + 1 record for q
     }
   }
 
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
         const uint32_t sub = S.subtree[node];
         if (sub == 1u) {
           const uint32_t mM = S.meta[meta_idx(S, selM, b, site)];
-          const uint32_t leaf_state = (mM >> 7) ^ (mM & 1u);
+          const uint32_t leaf_state = (mM >> EPV_INIT_SHIFT) ^ (mM & 1u);
           q0 = leaf_state ? 0.0 : 1.0;
           q1 = leaf_state ? 1.0 : 0.0;
         } else {
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
     unsigned long long multi = 0ull;   // ... of those, the branches with an even bucket bit (K = 2 or K >= 4)
     unsigned long long deep = 0ull;    // ... and those with K >= 3 (second region)
     {
-      const uint32_t root_state = run ? (uint32_t)(S.meta[meta_idx(S, selM, 0u, site)] >> 7) : 0u;
+      const uint32_t root_state = run ? (uint32_t)(S.meta[meta_idx(S, selM, 0u, site)] >> EPV_INIT_SHIFT) : 0u;
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t b = node - 1u;
         if (run) {
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
           // only a dirty branch is ever read back (by epv_mh_jumps_kernel)
           if ((K & 63u) && !clean) states[(K - 1u) >> 6] = word;
           // proposal so far: no jumps; epv_mh_jumps_kernel fills dirty branches in
-          S.meta[meta_idx(S, selM ^ 1u, b, site)] = (uint8_t)(start_state << 7);
+          S.meta[meta_idx(S, selM ^ 1u, b, site)] = (epv_meta_t)(start_state << EPV_INIT_SHIFT);
           regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children
           orig_proposal += lp;
           if (!clean) {
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
     PathRef L, R;
     L.j = R.j = nullptr; L.nj = R.nj = 0; L.init = R.init = 0;
     const uint64_t *states = nullptr;
-    uint8_t *meta = nullptr;
+    epv_meta_t *meta = nullptr;
     double *dst = nullptr;
     double seg_start = 0.0;    // time of the previous neighbour jump (Segment.cpp's prev_time)
     double time_passed = 0.0;  // running SUM of segment lengths (SingleSiteSampler.cpp:218)
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
       states = S.prop_states + ((uint64_t)b * S.phase_cap + ptid) * S.W;
       meta = S.meta + meta_idx(S, selP, b, site);
       dst = S.jumps + ((uint64_t)selP * B + b) * C * n + site;
-      start_state = (uint32_t)(*meta >> 7);
+      start_state = (uint32_t)(*meta >> EPV_INIT_SHIFT);
       prev = start_state;
       trip0 = 4u * L.init + R.init;
       tl = L.nj ? L.j[0] : EPV_INF;
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
             cnt = (start_state ^ prev) & 1u;  // keep the end-state parity; the proposal is rejected
             S.prop_flag[ptid] = 1u;
           }
-          *meta = (uint8_t)((start_state << 7) | cnt);
+          *meta = (epv_meta_t)((start_state << EPV_INIT_SHIFT) | cnt);
           active = false;
         } else {
           if (take_left) { trip0 ^= 4u; ++i; tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF; }
@@ -986,8 +986,8 @@ __global__ __launch_bounds__(256) void epv_init_tasks_kernel(EpvDev S, uint32_t 
   const bool valid = site <= last;
   if (valid) {
     const uint32_t sel = S.sel[site];
-    const uint32_t root = (uint32_t)(S.meta[meta_idx(S, sel, 0u, site)] >> 7);
-    S.meta[meta_idx(S, sel ^ 1u, 0u, site)] = (uint8_t)(root << 7);
+    const uint32_t root = (uint32_t)(S.meta[meta_idx(S, sel, 0u, site)] >> EPV_INIT_SHIFT);
+    S.meta[meta_idx(S, sel ^ 1u, 0u, site)] = (epv_meta_t)(root << EPV_INIT_SHIFT);
     S.prop_states[tid * S.W] = leaf[site] ? 1ull : 0ull;
     S.prop_flag[tid] = 0u;
   }
@@ -1034,11 +1034,11 @@ __global__ void epv_init_ends_kernel(EpvDev S, const uint8_t *leaf, uint32_t see
   if (threadIdx.x > 1) return;
   const uint64_t site = threadIdx.x ? S.n - 1u : 0u;
   const uint32_t sel = S.sel[site];
-  const uint32_t root = (uint32_t)(S.meta[meta_idx(S, sel, 0u, site)] >> 7);
+  const uint32_t root = (uint32_t)(S.meta[meta_idx(S, sel, 0u, site)] >> EPV_INIT_SHIFT);
   if (root != (uint32_t)leaf[site]) {
     const double u = epv_keyed_block(seed_lo, seed_hi, (uint32_t)(S.g0 + site), EPV_INIT_SWEEP, 1u, 0u, 0u, 0u).d0;
     S.jumps[((uint64_t)sel * S.B) * S.C * S.n + site] = u * (T - 0.0) + 0.0;
-    S.meta[meta_idx(S, sel, 0u, site)] = (uint8_t)((root << 7) | 1u);
+    S.meta[meta_idx(S, sel, 0u, site)] = (epv_meta_t)((root << EPV_INIT_SHIFT) | 1u);
   }
 }
 
@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void indep_upward(const EpvDev &S, const EpvIndepCons
     const uint32_t sub = S.subtree[node];
     if (sub == 1u) {
       const uint32_t m = S.meta[meta_idx(S, sel, node - 1u, site)];
-      const uint32_t leaf_state = (m >> 7) ^ (m & 1u);
+      const uint32_t leaf_state = (m >> EPV_INIT_SHIFT) ^ (m & 1u);
       a = leaf_state ? 0.0 : 1.0;
       b = leaf_state ? 1.0 : 0.0;
     } else {
@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(64) void epv_indep_propose_kernel(EpvDev S, const E
   if (valid) {
     sel = S.sel[site];
     indep_upward(S, ic, sel, site, fh);
-    root_state = (uint32_t)(S.meta[meta_idx(S, sel, 0u, site)] >> 7);
+    root_state = (uint32_t)(S.meta[meta_idx(S, sel, 0u, site)] >> EPV_INIT_SHIFT);
     S.prop_flag[tid] = 0u;
   }
   const uint32_t gsite = (uint32_t)(S.g0 + site);
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(64) void epv_indep_propose_kernel(EpvDev S, const E
       const bool clean = (sampled == start) &&
                          (1.0 - sblk.d1 < nojump_bound(S.blen[node] * (start ? r1 : r0)));
       S.prop_states[((uint64_t)b * S.phase_cap + tid) * S.W] = sampled;
-      S.meta[meta_idx(S, sel ^ 1u, b, site)] = (uint8_t)(start << 7);
+      S.meta[meta_idx(S, sel ^ 1u, b, site)] = (epv_meta_t)(start << EPV_INIT_SHIFT);
       me[2] = epv_u2d((uint64_t)sampled);   // proposal end state for the children
       if (!clean) dirty |= 1ull << (b & 63u);
     }
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(256) void epv_scale_kernel(EpvDev S, const double *
   const uint32_t buf = S.sel[site];
   for (uint32_t b = 0; b < S.B; ++b) {
     const uint64_t plane = (uint64_t)buf * S.B + b;
-    const uint32_t nj = S.meta[meta_idx(S, buf, b, site)] & 127u;
+    const uint32_t nj = S.meta[meta_idx(S, buf, b, site)] & EPV_NJ_MASK;
     double *j = S.jumps + plane * S.C * S.n + site;
     const double sc = scale[b + 1];
     for (uint32_t k = 0; k < nj; ++k) j[(uint64_t)k * S.n] *= sc;
@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(256) void epv_scatter_kernel(EpvDev S, const uint8_
   const uint64_t b = e / S.n, site = e % S.n;
   const uint64_t o = offsets[e];
   const uint32_t cnt = (uint32_t)(offsets[e + 1] - o);
-  S.meta[meta_idx(S, 0u, (uint32_t)b, site)] = (uint8_t)((init[e] ? 0x80u : 0u) | cnt);  // buffer 0
+  S.meta[meta_idx(S, 0u, (uint32_t)b, site)] = (epv_meta_t)((init[e] ? (1u << EPV_INIT_SHIFT) : 0u) | cnt);  // buffer 0
   double *j = S.jumps + b * S.C * S.n + site;
   for (uint32_t k = 0; k < cnt; ++k) j[(uint64_t)k * S.n] = jumps_csr[o + k];
   if (b == 0) { S.sel[site] = 0; S.tri[site] = 0.0; }
@@ -1426,9 +1426,9 @@ __global__ __launch_bounds__(256) void epv_count_kernel(EpvDev S, uint8_t *init_
   const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (uint64_t)S.B * S.n) return;
   const uint64_t b = e / S.n, site = e % S.n;
-  const uint8_t m = S.meta[meta_idx(S, S.sel[site], (uint32_t)b, site)];
-  init_out[e] = m >> 7;
-  counts[e] = m & 127u;
+  const epv_meta_t m = S.meta[meta_idx(S, S.sel[site], (uint32_t)b, site)];
+  init_out[e] = m >> EPV_INIT_SHIFT;
+  counts[e] = m & EPV_NJ_MASK;
 }
 
 __global__ __launch_bounds__(256) void epv_gather_kernel(EpvDev S, const uint64_t *offsets,
@@ -1437,17 +1437,20 @@ __global__ __launch_bounds__(256) void epv_gather_kernel(EpvDev S, const uint64_
   if (e >= (uint64_t)S.B * S.n) return;
   const uint64_t b = e / S.n, site = e % S.n;
   const uint64_t plane = (uint64_t)S.sel[site] * S.B + b;
-  const uint32_t cnt = S.meta[meta_idx(S, S.sel[site], (uint32_t)b, site)] & 127u;
+  const uint32_t cnt = S.meta[meta_idx(S, S.sel[site], (uint32_t)b, site)] & EPV_NJ_MASK;
   const double *j = S.jumps + plane * S.C * S.n + site;
   const uint64_t o = offsets[e];
   for (uint32_t k = 0; k < cnt; ++k) jumps_csr[o + k] = j[(uint64_t)k * S.n];
 }
 
 // ------------------------------------------------ halo columns (site-sharded runs)
-// packed column = [B bytes meta (current path)] padded to 8, [B*C doubles jumps],
+// packed column = [B meta words (current path)] padded to 8 bytes, [B*C doubles jumps],
 // [3 doubles tri(s-1), tri(s), tri(s+1)]
+__device__ __forceinline__ uint64_t epv_col_meta_bytes(uint32_t B) {
+  return ((uint64_t)B * sizeof(epv_meta_t) + 7u) & ~7ull;
+}
 __device__ __forceinline__ uint64_t epv_col_bytes(uint32_t B, uint32_t C) {
-  return (((uint64_t)B + 7u) & ~7ull) + ((uint64_t)B * C + 3u) * 8u;
+  return epv_col_meta_bytes(B) + ((uint64_t)B * C + 3u) * 8u;
 }
 __global__ void epv_pack_columns_kernel(EpvDev S, uint64_t first, uint64_t count,
                                         uint8_t *packed) {
@@ -1455,13 +1458,13 @@ __global__ void epv_pack_columns_kernel(EpvDev S, uint64_t first, uint64_t count
   if (c >= count) return;
   const uint64_t site = first + c;
   const uint64_t cb = epv_col_bytes(S.B, S.C);
-  uint8_t *col = packed + c * cb;
-  double *dj = reinterpret_cast<double *>(col + (((uint64_t)S.B + 7u) & ~7ull));
+  epv_meta_t *col = reinterpret_cast<epv_meta_t *>(packed + c * cb);
+  double *dj = reinterpret_cast<double *>(packed + c * cb + epv_col_meta_bytes(S.B));
   const uint32_t buf = S.sel[site];
   for (uint32_t i = threadIdx.x; i < S.B * S.C; i += blockDim.x) {
     const uint32_t b = i / S.C, k = i % S.C;
     const uint64_t plane = (uint64_t)buf * S.B + b;
-    const uint32_t nj = S.meta[meta_idx(S, buf, b, site)] & 127u;
+    const uint32_t nj = S.meta[meta_idx(S, buf, b, site)] & EPV_NJ_MASK;
     dj[i] = k < nj ? S.jumps[(plane * S.C + k) * S.n + site] : 0.0;
   }
   for (uint32_t b = threadIdx.x; b < S.B; b += blockDim.x)
@@ -1477,12 +1480,12 @@ __global__ void epv_unpack_columns_kernel(EpvDev S, uint64_t first, uint64_t cou
   if (c >= count) return;
   const uint64_t site = first + c;
   const uint64_t cb = epv_col_bytes(S.B, S.C);
-  const uint8_t *col = packed + c * cb;
-  const double *dj = reinterpret_cast<const double *>(col + (((uint64_t)S.B + 7u) & ~7ull));
+  const epv_meta_t *col = reinterpret_cast<const epv_meta_t *>(packed + c * cb);
+  const double *dj = reinterpret_cast<const double *>(packed + c * cb + epv_col_meta_bytes(S.B));
   const uint32_t buf = S.sel[site];  // overwrite the current buffer in place
   for (uint32_t i = threadIdx.x; i < S.B * S.C; i += blockDim.x) {
     const uint32_t b = i / S.C, k = i % S.C;
-    const uint32_t nj = col[b] & 127u;
+    const uint32_t nj = col[b] & EPV_NJ_MASK;
     if (k < nj) S.jumps[(((uint64_t)buf * S.B + b) * S.C + k) * S.n + site] = dj[i];
   }
   for (uint32_t b = threadIdx.x; b < S.B; b += blockDim.x)

@@ -119,14 +119,14 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
   const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
   const uint32_t tab_dbl = S.B * 4u * EPV_SEGTAB_DBL;
   const uint32_t regA_dbl = ((S.N * 64u + 1u) / 2u + 1u) & ~1u;
-  const uint32_t mc_dbl = (3u * S.B * 64u + 15u) / 16u * 2u;     // meta bytes of the three columns
+  const uint32_t mc_dbl = (3u * S.B * 64u * (uint32_t)sizeof(epv_meta_t) + 15u) / 16u * 2u;   // meta words of the three columns
   double *s_const = s_mem;
   double *s_tab = s_mem + const_dbl;
   uint32_t *regA = reinterpret_cast<uint32_t *>(s_mem + const_dbl + tab_dbl);
   // s_meta[(which * B + b) * 64 + lane], which = 0 left, 1 right, 2 this site: fetched ONCE, in one
   // batch of independent loads; the four passes below then read LDS instead of paying a global
   // round trip per branch (the kernel is bound by memory latency, not by issue)
-  uint8_t *s_meta = reinterpret_cast<uint8_t *>(s_mem + const_dbl + tab_dbl + regA_dbl);
+  epv_meta_t *s_meta = reinterpret_cast<epv_meta_t *>(s_mem + const_dbl + tab_dbl + regA_dbl);
   const int lane = epv_lane();
   // GPOOL: rows of 64 interleaved records (row r of lane l at (r * 64 + l) * 2 doubles), then
   // the flat heavy list; LDS: records packed by a wave prefix sum, the heavy list behind them
@@ -156,10 +156,10 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
       const uint32_t mL = S.meta[meta_idx(S, selL, b, site - 1)];
       const uint32_t mR = S.meta[meta_idx(S, selR, b, site + 1)];
       const uint32_t mM = S.meta[meta_idx(S, selM, b, site)];
-      s_meta[(0u * B + b) * 64u + lane] = (uint8_t)mL;
-      s_meta[(1u * B + b) * 64u + lane] = (uint8_t)mR;
-      s_meta[(2u * B + b) * 64u + lane] = (uint8_t)mM;
-      const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
+      s_meta[(0u * B + b) * 64u + lane] = (epv_meta_t)mL;
+      s_meta[(1u * B + b) * 64u + lane] = (epv_meta_t)mR;
+      s_meta[(2u * B + b) * 64u + lane] = (epv_meta_t)mM;
+      const uint32_t K = (mL & EPV_NJ_MASK) + (mR & EPV_NJ_MASK) + 1u;
       need_rec += K + (S.subtree[b + 1u] != 1u ? 1u : 0u);
       if (K >= 2u) heavy += K;
     }
@@ -186,11 +186,11 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t b = node - 1u;
         const uint32_t cL = s_meta[(0u * B + b) * 64u + lane], cR = s_meta[(1u * B + b) * 64u + lane];
-        const uint32_t K = (cL & 127u) + (cR & 127u) + 1u;
+        const uint32_t K = (cL & EPV_NJ_MASK) + (cR & EPV_NJ_MASK) + 1u;
         if (K < 2u) continue;
         PathRef L, R;
-        L.j = S.jumps + ((uint64_t)selL * B + b) * S.C * n + (site - 1); L.nj = cL & 127u; L.init = cL >> 7;
-        R.j = S.jumps + ((uint64_t)selR * B + b) * S.C * n + (site + 1); R.nj = cR & 127u; R.init = cR >> 7;
+        L.j = S.jumps + ((uint64_t)selL * B + b) * S.C * n + (site - 1); L.nj = cL & EPV_NJ_MASK; L.init = cL >> EPV_INIT_SHIFT;
+        R.j = S.jumps + ((uint64_t)selR * B + b) * S.C * n + (site + 1); R.nj = cR & EPV_NJ_MASK; R.init = cR >> EPV_INIT_SHIFT;
         uint32_t trip0 = 4u * L.init + R.init, i = 0, j = 0;
         double seg_start = 0.0;
         double tl = L.nj ? L.j[0] : EPV_INF, tr = R.nj ? R.j[0] : EPV_INF;
@@ -238,13 +238,13 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
       for (uint32_t node = S.N - 1u; node >= 1u; --node) {
         const uint32_t b = node - 1u;
         const uint32_t mL = s_meta[(0u * B + b) * 64u + lane], mR = s_meta[(1u * B + b) * 64u + lane];
-        const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
+        const uint32_t K = (mL & EPV_NJ_MASK) + (mR & EPV_NJ_MASK) + 1u;
         const uint32_t sub = S.subtree[node];
         off -= K + (sub != 1u ? 1u : 0u);
         double n0 = 1.0, n1 = 1.0;
         if (sub == 1u) {
           const uint32_t mM = s_meta[(2u * B + b) * 64u + lane];
-          const uint32_t leaf_state = (mM >> 7) ^ (mM & 1u);
+          const uint32_t leaf_state = (mM >> EPV_INIT_SHIFT) ^ (mM & 1u);
           n0 = leaf_state ? 0.0 : 1.0;
           n1 = leaf_state ? 1.0 : 0.0;
         } else {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
         }
         regA[node * 64u + lane] = off;
         if (K == 1u) {
-          const double *t = s_tab + (size_t)(b * 4u + 2u * (mL >> 7) + (mR >> 7)) * EPV_SEGTAB_DBL;
+          const double *t = s_tab + (size_t)(b * 4u + 2u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT)) * EPV_SEGTAB_DBL;
           const double P00 = t[0], P11 = t[1];
           const double P01 = 1.0 - P00, P10 = 1.0 - P11;
           double *rec = my + (size_t)off * RS;
@@ -284,13 +284,13 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
     //         by epv_mh_jumps_kernel for the dirty branches only (see epv_kernels.h).  The node
     //         loop is wave-uniform: the task flush inside it is a wave-wide operation.
     unsigned long long dirty = 0ull, multi = 0ull, deep = 0ull;
-    const uint32_t root_state = run ? (uint32_t)(s_meta[(2u * B) * 64u + lane] >> 7) : 0u;
+    const uint32_t root_state = run ? (uint32_t)(s_meta[(2u * B) * 64u + lane] >> EPV_INIT_SHIFT) : 0u;
     uint32_t hcur = hbase;
     for (uint32_t node = 1u; node < S.N; ++node) {
       const uint32_t b = node - 1u;
       if (run) {
         const uint32_t mL = s_meta[(0u * B + b) * 64u + lane], mR = s_meta[(1u * B + b) * 64u + lane];
-        const uint32_t K = (mL & 127u) + (mR & 127u) + 1u;
+        const uint32_t K = (mL & EPV_NJ_MASK) + (mR & EPV_NJ_MASK) + 1u;
         const uint32_t off = regA[node * 64u + lane];
         const uint32_t par = S.parent[node];
         const uint32_t start_state = (par == 0u) ? root_state : (regA[par * 64u + lane] >> 31);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
           const bool last_seg = (k + 1u == K);
           double nxt0, nxt1;
           if (last_seg && leaf) {          // q of a leaf: the observed state
-            const uint32_t leaf_state = (mM >> 7) ^ (mM & 1u);
+            const uint32_t leaf_state = (mM >> EPV_INIT_SHIFT) ^ (mM & 1u);
             nxt0 = leaf_state ? 0.0 : 1.0;
             nxt1 = leaf_state ? 1.0 : 0.0;
           } else {
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
           }
           double PT0, nb, u_end, u_first;
           if (K == 1u) {
-            const double *t = s_tab + (size_t)(b * 4u + 2u * (mL >> 7) + (mR >> 7)) * EPV_SEGTAB_DBL;
+            const double *t = s_tab + (size_t)(b * 4u + 2u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT)) * EPV_SEGTAB_DBL;
             PT0 = prev ? t[3] : t[2];
             nb = prev ? t[5] : t[4];
             const epv_block2 blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, 0u, 0u, 0u);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
         if ((K & 63u) && !clean) states[(K - 1u) >> 6] = word;   // only a dirty branch is read back
         regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children
         // same as the current path?  (no jumps on either, same start state)
-        ident = ident && clean && mM == (start_state << 7);
+        ident = ident && clean && mM == (start_state << EPV_INIT_SHIFT);
         if (!clean) {
           dirty |= 1ull << (b & 63u);
           if (K == 2u || K >= 4u) multi |= 1ull << (b & 63u);   // four buckets by segment count
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t par = S.parent[node];
         const uint32_t st = (par == 0u) ? root_state : (regA[par * 64u + lane] >> 31);
-        S.meta[meta_idx(S, selM ^ 1u, node - 1u, site)] = (uint8_t)(st << 7);
+        S.meta[meta_idx(S, selM ^ 1u, node - 1u, site)] = (epv_meta_t)(st << EPV_INIT_SHIFT);
       }
       S.prop_flag[tid] = 0u;
     }

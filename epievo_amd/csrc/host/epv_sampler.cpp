@@ -15,7 +15,7 @@ namespace epv {
 
 namespace {
 const uint64_t kBlock = 256;   // sites per level-0 block of the statistics tree
-const uint32_t kMaxCap = 127;
+const uint32_t kMaxCap = 2047;   // EPV_MAX_CAP: 2 C + 1 segments must fit the 12-bit segment field of the Philox address
 
 uint64_t round_to(double x, uint64_t unit) { return (uint64_t)(x / (double)unit + 0.5) * unit; }
 

@@ -33,6 +33,8 @@ class _Counters(C.Structure):
                 ("n_sweeps", C.c_uint64), ("reserved", C.c_uint64)]
 
 
+MAX_CAPACITY = 2047    # EPV_MAX_CAP: jump slots per (site, branch)
+
 ABI_SYMBOLS = [
     "epv_create", "epv_destroy", "epv_last_error", "epv_set_tree", "epv_set_model",
     "epv_upload_paths", "epv_set_capacity", "epv_get_capacity", "epv_init_paths_indep", "epv_indep_expectation",
@@ -180,8 +182,8 @@ class DeviceSampler:
         if rc == EPV_ERR_CAPACITY and self.auto_grow:
             msg = self.L.epv_last_error(self.h).decode()
             cap = self.capacity()
-            if cap < 127:
-                self.set_capacity(min(127, 2 * cap))
+            if cap < MAX_CAPACITY:
+                self.set_capacity(min(MAX_CAPACITY, 2 * cap))
                 self.capacity_events.append(msg)
                 return
         self._ck(rc)

@@ -86,7 +86,8 @@ int epv_set_model(epv_ctx *ctx, const double *triplet_rates, const double *T);
 
 /* Upload all paths (replaces handing `vector<vector<Path>>&` to reset()).
  * `capacity` is the fixed number of jump slots kept per (site, branch) on the device
- * (1..127); 0 picks max(16, 2*max_jumps_in_input + 8).  A proposal that would need
+ * (1..2047: a branch has at most 2 * capacity + 1 segments and the segment field of the random
+ * stream's address has 12 bits); 0 picks max(16, 2*max_jumps_in_input + 8).  A proposal that would need
  * more is rejected and counted (epv_counters.n_overflow) and the MCMC call that saw it
  * returns EPV_ERR_CAPACITY after completing -- re-upload with a larger capacity.
  * `global_site_offset`: index of local site 0 in the whole genome (0 on one GPU);
@@ -100,7 +101,7 @@ int epv_upload_paths(epv_ctx *ctx, uint64_t n_sites, const uint8_t *init_state,
  * stay valid.  The reference's std::vector paths grow on demand; this is the equivalent a
  * wrapper calls after EPV_ERR_CAPACITY (the run that reported it is a valid chain on the
  * histories with at most `capacity` jumps per branch).  Fails with EPV_ERR_CAPACITY when a
- * resident path has more jumps than `capacity`; capacity is clamped to 1..127. */
+ * resident path has more jumps than `capacity`; capacity is clamped to 1..2047. */
 int epv_set_capacity(epv_ctx *ctx, uint32_t capacity);
 int epv_get_capacity(epv_ctx *ctx, uint32_t *capacity);
 int epv_set_options(epv_ctx *ctx, uint32_t flags);

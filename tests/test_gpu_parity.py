@@ -207,3 +207,40 @@ def test_set_capacity_and_auto_grow_match_oracle():
     assert d.counters()["overflow"] == o.counters()["overflow"] > 0
     # tri_llh cache survived the re-striding
     assert np.array_equal(d.tri_llh(), o.tri_llh())
+
+
+@pytest.mark.parametrize("T,n", [(20.0, 2000), (150.0, 400)])
+def test_long_branch_beyond_127_jumps(T, n):
+    """Path::jumps is an unbounded std::vector in the reference (Path.hpp:52).  The device keeps
+    fixed-stride slots whose count is a 15-bit field: a branch of length 20 (tens of jumps per
+    path) and one of length 150 (paths with more than 127 jumps, beyond the 7-bit field of round 1)
+    run without a single rejection by capacity, bit-identical to the oracle."""
+    from epievo_amd import host
+    from common import ref_test_model
+    model = ref_test_model()
+    tree = host.Tree.single_branch(T)
+    fp = host.simulate(model, tree, n, 9)
+    maxj = int(fp.counts().max())
+    if T > 100:
+        assert maxj > 127
+    d = _dev(tree, model, fp, 0)                   # the library's default: max(16, 2 maxj + 8)
+    cap = d.capacity()
+    assert cap == max(16, 2 * maxj + 8)
+    assert orc.paths_equal(d.paths(), fp)
+    o = orc.Oracle(tree, model, fp, "B", cap=cap, seed=41)
+    d.reset(); o.reset()
+    assert np.array_equal(d.tri_llh(), o.tri_llh())
+    for w in range(2):
+        assert d.sweep(1, 41, sweep_base=w) == o.sweep(w)
+    assert d.counters()["overflow"] == o.counters()["overflow"] == 0
+    assert orc.paths_equal(d.paths(), o.paths())
+    Jd, Dd = d.suffstats()
+    Jo, Do = o.suffstats()
+    assert np.array_equal(Jd, Jo) and np.array_equal(Dd, Do)
+    # growing on demand past the old ceiling: a tiny start capacity is doubled until it fits
+    g = _dev(tree, model, fp, maxj)
+    g.auto_grow = True
+    g.reset()
+    for w in range(3):
+        g.sweep(1, 41, sweep_base=w)
+    assert g.capacity() > maxj and g.capacity_events
