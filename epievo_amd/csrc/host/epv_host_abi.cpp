@@ -146,6 +146,102 @@ EPVH_API int epvh_read_tree(const char *tree_file, int max_nodes, uint32_t *subt
   } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 
+// the tree of a Newick file printed back (Tree::newick) -- the -t output of the drop-in CLIs
+EPVH_API int epvh_tree_newick(const char *tree_file, char *out, int out_len) {
+  try {
+    put_text(epv::Tree::read(tree_file).newick(), out, out_len);
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// ---- global_jumps and states files (epievo_sim's outputs)
+namespace {
+std::vector<std::string> split_lines(const char *joined) {
+  std::vector<std::string> names;
+  std::string cur;
+  for (const char *p = joined;; ++p) {
+    if (*p == '\n' || *p == '\0') { names.push_back(cur); cur.clear(); if (!*p) break; }
+    else cur.push_back(*p);
+  }
+  return names;
+}
+struct GlobalFile { std::vector<uint8_t> root; std::vector<std::string> names; std::vector<std::vector<epv::GlobalJump>> paths; };
+struct StatesFile { std::vector<std::string> names; std::vector<std::vector<uint8_t>> states; };
+}  // namespace
+
+EPVH_API int epvh_write_global_jumps(const char *file, int n_nodes, const char *names_joined, uint64_t n_sites,
+                                     const uint8_t *root, const uint64_t *node_offsets, const double *times,
+                                     const uint64_t *positions) {
+  try {
+    std::vector<std::vector<epv::GlobalJump>> paths(n_nodes);
+    for (int b = 1; b < n_nodes; ++b)
+      for (uint64_t i = node_offsets[b]; i < node_offsets[b + 1]; ++i) paths[b].push_back({times[i], (size_t)positions[i]});
+    epv::write_global_jumps(file, split_lines(names_joined), std::vector<uint8_t>(root, root + n_sites), paths);
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+EPVH_API void *epvh_read_global_jumps(const char *file, int *n_nodes, uint64_t *n_sites, uint64_t *total) {
+  try {
+    GlobalFile *g = new GlobalFile();
+    epv::read_global_jumps(file, g->root, g->names, g->paths);
+    *n_nodes = (int)g->paths.size();
+    *n_sites = g->root.size();
+    uint64_t tot = 0;
+    for (const auto &v : g->paths) tot += v.size();
+    *total = tot;
+    return g;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+EPVH_API void epvh_global_jumps_copy(void *h, uint8_t *root, uint64_t *node_offsets, double *times,
+                                     uint64_t *positions, char *names, int names_len) {
+  GlobalFile *g = static_cast<GlobalFile *>(h);
+  std::memcpy(root, g->root.data(), g->root.size());
+  uint64_t at = 0;
+  for (size_t b = 0; b < g->paths.size(); ++b) {
+    node_offsets[b] = at;
+    for (const epv::GlobalJump &j : g->paths[b]) { times[at] = j.timepoint; positions[at] = j.position; ++at; }
+  }
+  node_offsets[g->paths.size()] = at;
+  std::string joined;
+  for (size_t i = 0; i < g->names.size(); ++i) joined += (i ? "\n" : "") + g->names[i];
+  put_text(joined, names, names_len);
+  delete g;
+}
+
+// states[seq][site] row-major; `names_joined` = the column names of the header line
+EPVH_API int epvh_write_states(const char *file, int only_leaves, int n_nodes, const uint32_t *subtree,
+                               const char *names_joined, uint64_t n_sites, const uint8_t *states) {
+  try {
+    epv::Tree t;
+    t.subtree_sizes.assign(subtree, subtree + n_nodes);
+    t.parent_ids.assign(n_nodes, 0);
+    t.branches.assign(n_nodes, 0.0);
+    t.node_names = split_lines(names_joined);
+    std::vector<std::vector<uint8_t>> seqs(n_nodes);
+    for (int b = 0; b < n_nodes; ++b) seqs[b].assign(states + (uint64_t)b * n_sites, states + (uint64_t)(b + 1) * n_sites);
+    epv::write_states(file, only_leaves != 0, t, seqs);
+    return 0;
+  } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+EPVH_API void *epvh_read_states(const char *file, int *n_seqs, uint64_t *n_sites) {
+  try {
+    StatesFile *f = new StatesFile();
+    epv::read_states_file(file, f->names, f->states);
+    *n_seqs = (int)f->states.size();
+    *n_sites = f->states.empty() ? 0 : f->states[0].size();
+    return f;
+  } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+EPVH_API void epvh_states_copy(void *h, uint8_t *states, char *names, int names_len) {
+  StatesFile *f = static_cast<StatesFile *>(h);
+  uint64_t at = 0;
+  for (const auto &sq : f->states) { std::memcpy(states + at, sq.data(), sq.size()); at += sq.size(); }
+  std::string joined;
+  for (size_t i = 0; i < f->names.size(); ++i) joined += (i ? "\n" : "") + f->names[i];
+  put_text(joined, names, names_len);
+  delete f;
+}
+
 // ---- site-independent stage of epievo_initialization (host parts)
 EPVH_API int epvh_indep_m_step(int optimize_branches, int n_nodes, const double *J, const double *D,
                                double *rates, double *branches) {

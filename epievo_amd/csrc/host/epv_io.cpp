@@ -17,6 +17,7 @@ namespace {
 struct Node {
   std::string name;
   double len = 0.0;
+  bool generated = false;   // the name was made up by name_missing
   std::vector<Node> child;
 };
 
@@ -53,7 +54,7 @@ Node parse_node(const std::string &rep) {
 // PhyloTreePreorder.cpp:79-86: the counter is passed BY VALUE into the children, so
 // unnamed siblings can share a generated name -- kept for drop-in fidelity.
 void name_missing(Node &nd, size_t count) {
-  if (nd.name.empty()) nd.name = "node_" + std::to_string(count++);
+  if (nd.name.empty()) { nd.name = "node_" + std::to_string(count++); nd.generated = true; }
   for (Node &c : nd.child) name_missing(c, count);
 }
 
@@ -62,6 +63,7 @@ uint32_t flatten(const Node &nd, Tree &t) {
   t.subtree_sizes.push_back(1);
   t.branches.push_back(nd.len);
   t.node_names.push_back(nd.name);
+  t.name_generated.push_back(nd.generated);
   for (const Node &c : nd.child) t.subtree_sizes[me] += flatten(c, t);
   return t.subtree_sizes[me];
 }
@@ -80,7 +82,10 @@ void newick_of(const Tree &t, int node, std::ostringstream &oss) {
   // each reference node formats through its own fresh ostringstream (default precision)
   std::ostringstream num;
   num << t.branches[node];
-  oss << t.node_names[node] << ':' << num.str();
+  // the mains print the tree they READ (names are generated on TreeHelper's private copy,
+  // TreeHelper.cpp:43-46), so a node without a name in the input stays without one
+  const bool gen = (size_t)node < t.name_generated.size() && t.name_generated[node];
+  oss << (gen ? std::string() : t.node_names[node]) << ':' << num.str();
 }
 
 }  // namespace

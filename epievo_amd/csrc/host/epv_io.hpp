@@ -18,6 +18,7 @@ struct Tree {
   std::vector<uint32_t> parent_ids;
   std::vector<double> branches;
   std::vector<std::string> node_names;
+  std::vector<bool> name_generated;   // node_<k> made up for an unnamed node: not printed back
   int n_nodes() const { return (int)subtree_sizes.size(); }
   bool is_leaf(int node) const { return subtree_sizes[node] == 1; }
 

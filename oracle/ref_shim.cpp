@@ -32,6 +32,9 @@
 #include "IndepSite.hpp"
 #include "TripletSampler.hpp"
 #include "GlobalJump.hpp"
+#include "PhyloTreePreorder.hpp"
+#include "epievo_utils.hpp"
+#include <fstream>
 
 using std::vector;
 using std::array;
@@ -422,6 +425,157 @@ void ref_kat_mt_canonical(uint64_t seed, uint64_t n, double *out) {
   std::mt19937 g(seed);
   std::uniform_real_distribution<double> u(0.0, 1.0);
   for (uint64_t i = 0; i < n; ++i) out[i] = u(g);
+}
+
+
+/* ---------------------------------------------------------------- file formats
+ * The reference's own writers and readers, so that tests can pin the product's text IO
+ * (epv_io.cpp, epv_forward.cpp) byte for byte and value for value.  local_paths: rows are the
+ * LINKED operator<<(ostream&, const Path&) (Path.cpp:62-71); the three lines around it
+ * ("NODE:<name>", "<site>\t<path>\n") are spelled as the static writers of the un-buildable
+ * mains spell them (epievo_est_params_histories.cpp:56-75).  Readers: read_paths (Path.cpp:123-148),
+ * read_pathfile_global / write_root_to_pathfile_global / append_to_pathfile_global
+ * (GlobalJump.cpp:71-140), read_states_file (epievo_utils.cpp:90-125), PhyloTree's operator>> and
+ * Newick_format (PhyloTree.cpp:110-122,189-203).  `names` are '\n'-joined. */
+namespace {
+vector<std::string> split_names(const char *joined) {
+  vector<std::string> out;
+  std::stringstream ss(joined);
+  std::string t;
+  while (std::getline(ss, t, '\n')) out.push_back(t);
+  return out;
+}
+struct LocalCache { vector<std::string> names; vector<vector<Path> > paths; } g_lp;
+struct GlobalCache { state_seq root; vector<std::string> names; vector<vector<GlobalJump> > paths; } g_gp;
+struct StatesCache { vector<std::string> names; vector<state_seq> states; } g_st;
+int put_names(const vector<std::string> &names, char *buf, uint64_t cap) {
+  std::string j;
+  for (size_t i = 0; i < names.size(); ++i) j += (i ? "\n" : "") + names[i];
+  if (j.size() + 1 > cap) return 1;
+  std::memcpy(buf, j.c_str(), j.size() + 1);
+  return 0;
+}
+}  // namespace
+
+int ref_write_local_paths(const char *file, int n_nodes, uint64_t n_sites, const char *names,
+                          const double *tot_times, const uint8_t *init, const uint64_t *offsets,
+                          const double *jumps) {
+  const vector<std::string> nm = split_names(names);
+  if ((int)nm.size() != n_nodes) return 1;
+  {
+    std::ofstream out(file);
+    if (!out) return 2;
+    out << "NODE:" << nm[0] << std::endl;
+  }
+  for (int b = 1; b < n_nodes; ++b) {
+    std::ofstream out(file, std::ofstream::app);
+    if (!out) return 2;
+    out << "NODE:" << nm[b] << std::endl;
+    for (uint64_t s = 0; s < n_sites; ++s) {
+      const uint64_t e = (uint64_t)(b - 1) * n_sites + s;
+      const Path p(init[e] != 0, tot_times[b], vector<double>(jumps + offsets[e], jumps + offsets[e + 1]));
+      out << s << '\t' << p << '\n';
+    }
+  }
+  return 0;
+}
+
+int ref_read_local_paths(const char *file, int *n_nodes, uint64_t *n_sites, uint64_t *total_jumps) {
+  g_lp = LocalCache();
+  try { read_paths(file, g_lp.names, g_lp.paths); } catch (const std::exception &) { return 1; }
+  *n_nodes = (int)g_lp.paths.size();
+  *n_sites = g_lp.paths.size() > 1 ? g_lp.paths[1].size() : 0;
+  uint64_t tot = 0;
+  for (size_t b = 1; b < g_lp.paths.size(); ++b)
+    for (const Path &p : g_lp.paths[b]) tot += p.jumps.size();
+  *total_jumps = tot;
+  return 0;
+}
+int ref_local_paths_copy(uint8_t *init, double *tot_times, uint64_t *offsets, double *jumps, char *names,
+                         uint64_t names_cap) {
+  uint64_t e = 0, at = 0;
+  for (size_t b = 1; b < g_lp.paths.size(); ++b) {
+    tot_times[b] = g_lp.paths[b].empty() ? 0.0 : g_lp.paths[b][0].tot_time;
+    for (const Path &p : g_lp.paths[b]) {
+      init[e] = p.init_state;
+      offsets[e++] = at;
+      for (double t : p.jumps) jumps[at++] = t;
+    }
+  }
+  offsets[e] = at;
+  return put_names(g_lp.names, names, names_cap);
+}
+
+int ref_write_global_jumps(const char *file, int n_nodes, const char *names, uint64_t n_sites,
+                           const uint8_t *root, const uint64_t *node_offsets, const double *times,
+                           const uint64_t *positions) {
+  const vector<std::string> nm = split_names(names);
+  if ((int)nm.size() != n_nodes) return 1;
+  try {
+    state_seq r(root, root + n_sites);
+    write_root_to_pathfile_global(file, nm[0], r);
+    for (int b = 1; b < n_nodes; ++b) {
+      vector<GlobalJump> v;
+      for (uint64_t i = node_offsets[b]; i < node_offsets[b + 1]; ++i) v.push_back(GlobalJump(times[i], positions[i]));
+      append_to_pathfile_global(file, nm[b], v);
+    }
+  } catch (const std::exception &) { return 2; }
+  return 0;
+}
+int ref_read_global_jumps(const char *file, int *n_nodes, uint64_t *n_sites, uint64_t *total) {
+  g_gp = GlobalCache();
+  try { read_pathfile_global(file, g_gp.root, g_gp.names, g_gp.paths); } catch (const std::exception &) { return 1; }
+  *n_nodes = (int)g_gp.paths.size();
+  *n_sites = g_gp.root.size();
+  uint64_t tot = 0;
+  for (const vector<GlobalJump> &v : g_gp.paths) tot += v.size();
+  *total = tot;
+  return 0;
+}
+int ref_global_jumps_copy(uint8_t *root, uint64_t *node_offsets, double *times, uint64_t *positions,
+                          char *names, uint64_t names_cap) {
+  for (size_t i = 0; i < g_gp.root.size(); ++i) root[i] = g_gp.root[i];
+  uint64_t at = 0;
+  for (size_t b = 0; b < g_gp.paths.size(); ++b) {
+    node_offsets[b] = at;
+    for (const GlobalJump &j : g_gp.paths[b]) { times[at] = j.timepoint; positions[at] = j.position; ++at; }
+  }
+  node_offsets[g_gp.paths.size()] = at;
+  return put_names(g_gp.names, names, names_cap);
+}
+
+int ref_read_states(const char *file, int *n_seqs, uint64_t *n_sites) {
+  g_st = StatesCache();
+  try { read_states_file(file, g_st.names, g_st.states); } catch (const std::exception &) { return 1; }
+  *n_seqs = (int)g_st.states.size();
+  *n_sites = g_st.states.empty() ? 0 : g_st.states[0].size();
+  return 0;
+}
+int ref_states_copy(uint8_t *states, char *names, uint64_t names_cap) {
+  uint64_t at = 0;
+  for (const state_seq &sq : g_st.states)
+    for (size_t i = 0; i < sq.size(); ++i) states[at++] = sq[i];
+  return put_names(g_st.names, names, names_cap);
+}
+
+/* parse Newick text with the reference and print it back (PhyloTree::Newick_format); also the
+ * pre-order arrays TreeHelper derives (TreeHelper.cpp:43-51) */
+int ref_newick_roundtrip(const char *text, char *out, uint64_t cap, int *n_nodes, uint32_t *parent,
+                         uint32_t *subtree, double *branches, char *names, uint64_t names_cap) {
+  PhyloTreePreorder t;
+  std::istringstream in(text);
+  if (!(in >> t)) return 1;
+  const std::string nw = t.Newick_format();
+  if (nw.size() + 1 > cap) return 2;
+  std::memcpy(out, nw.c_str(), nw.size() + 1);
+  TreeHelper th(t);
+  *n_nodes = (int)th.n_nodes;
+  for (size_t i = 0; i < th.n_nodes; ++i) {
+    parent[i] = (uint32_t)th.parent_ids[i];
+    subtree[i] = (uint32_t)th.subtree_sizes[i];
+    branches[i] = th.branches[i];
+  }
+  return put_names(th.node_names, names, names_cap);
 }
 
 }  // extern "C"

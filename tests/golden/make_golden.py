@@ -175,8 +175,35 @@ def kat():
     print("wrote kat")
 
 
+def text_fixtures():
+    """tests/golden/text/: files WRITTEN BY THE REFERENCE (its operator<<(Path) inside the mains'
+    three lines of glue; write_root_to_pathfile_global / append_to_pathfile_global), next to the
+    values they hold -- what tests/test_file_formats.py pins the product's reader and writer to
+    where oracle/_ref is absent."""
+    import test_file_formats as t
+    from common import config
+    d = os.path.join(HERE, "text")
+    os.makedirs(d, exist_ok=True)
+    tree, fp = t.awkward_paths("tree", 40)
+    tt = tree.branches * 1.0000000000000002 + 1e-17
+    t.ref_write_paths(os.path.join(d, "tree_n40.paths"), tree, tt, fp)
+    np.savez(os.path.join(d, "tree_n40.npz"), n_sites=fp.n_sites, n_nodes=fp.n_nodes, init=fp.init,
+             offsets=fp.offsets, jumps=fp.jumps, tot_times=tt, names=np.array(tree.node_names))
+    tree, n = config("tree"), 60
+    seqs, off, tj, pp = t._fwd(11, tree, n)
+    L = orc.ref_lib()
+    L.ref_write_global_jumps.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_uint64, t.u8p, t.u64p, t.dp, t.u64p]
+    root = np.ascontiguousarray(seqs[:n])
+    assert L.ref_write_global_jumps(os.path.join(d, "tree_n60.jumps").encode(), tree.n_nodes,
+                                    "\n".join(tree.node_names).encode(), n, orc._p(root, C.c_uint8),
+                                    orc._p(off, C.c_uint64), orc._p(tj, C.c_double), orc._p(pp, C.c_uint64)) == 0
+    np.savez(os.path.join(d, "tree_n60_global.npz"), root=root, off=off, t=tj, p=pp, names=np.array(tree.node_names))
+    print("wrote text fixtures")
+
+
 if __name__ == "__main__":
     assert orc.have_ref(), "build oracle/_ref first: make -C oracle ref"
+    text_fixtures()
     for cfg in ("pair", "tree"):
         for n in (16, 64, 1000):
             for seed in (1, 42):

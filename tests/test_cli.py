@@ -15,6 +15,17 @@ pytestmark = pytest.mark.gpu
 BIN = _build.BIN_DIR
 
 
+def _write_expected(path, tree, tot_times, fp):
+    """the EXPECTED local_paths bytes: written by the reference's own operator<<(Path) through
+    oracle/_ref wherever that exists (this container and the GPU box), so that the CLI's writer
+    is compared with the reference's and not with itself"""
+    if orc.have_ref():
+        from test_file_formats import ref_write_paths
+        ref_write_paths(path, tree, tot_times, fp)
+    else:
+        host.write_paths(path, tree.node_names, tot_times, fp)
+
+
 def _oracle_em(model, tree, fp, iters, burn, batch, seed, optimize):
     o = orc.Oracle(tree, model, fp, "B", cap=max(16, 2 * int(fp.counts().max()) + 8), seed=seed)
     branches = tree.branches.copy()
@@ -46,7 +57,7 @@ def test_est_params_histories_matches_oracle_em(tmp_path, cfg, optimize):
     d = str(tmp_path)
     open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
     open(d + "/t.nwk", "w").write(TREE_NWK_TEXT if cfg == "tree" else _newick(tree))
-    host.write_paths(d + "/in.paths", tree.node_names, tree.branches, fp)
+    _write_expected(d + "/in.paths", tree, tree.branches, fp)     # the CLI reads a reference-written file
     cmd = [os.path.join(BIN, "epievo_est_params_histories"), "-i", "2", "-B", "3", "-L", "2", "-s", "77",
            "-o", d + "/out.paths", "-p", d + "/out.param", "-t", d + "/out.nwk", "-v"]
     if optimize:
@@ -58,7 +69,7 @@ def test_est_params_histories_matches_oracle_em(tmp_path, cfg, optimize):
     assert len(lines) == 3 and len(lines[2].split("\t")) == 7      # itr T00 T11 b00 b11 acc llh
     m2, br, text, paths = _oracle_em(model, tree, fp, 2, 2, 3, 77, optimize)
     assert open(d + "/out.param").read() == text + "\n"
-    host.write_paths(d + "/exp.paths", tree.node_names, br, paths)
+    _write_expected(d + "/exp.paths", tree, br, paths)
     assert open(d + "/out.paths", "rb").read() == open(d + "/exp.paths", "rb").read()
     if optimize:
         t2 = host.Tree.read(d + "/out.nwk")
@@ -147,7 +158,7 @@ def test_initialization_matches_oracle_pipeline(tmp_path, optimize):
     m2, br2, llh, text = host.m_step(host.model_from_indep_rates(rates), br, Jt, Dt, optimize_branches=optimize)
     o.scale_jump_times(br2)
     assert open(d + "/out.param").read() == text + "\n"
-    host.write_paths(d + "/exp.paths", tree.node_names, br2, o.paths())
+    _write_expected(d + "/exp.paths", tree, br2, o.paths())
     assert open(d + "/out.paths", "rb").read() == open(d + "/exp.paths", "rb").read()
     # the fitted model is sane: positive rates, leaves kept
     out, names, tt = host.read_paths(d + "/out.paths")
