@@ -1129,6 +1129,66 @@ ORC_API uint64_t orc_exact_posterior(const double *rates, uint64_t n, const uint
   return kept;
 }
 
+/* The same on a TREE (MCMC_test.cpp runs a single branch; the sampler's real workload is a
+ * tree): the whole sequence evolves down every branch in pre-order from the fixed root sequence
+ * (SAMPLE_ROOT is false), the two end sites never jump (the sampler does not update them), and
+ * a history is kept only if every LEAF node ends in its observed sequence (leaf[node][site];
+ * rows of internal nodes are ignored).  Jm/Dm/J2/D2: [(b-1)*8 + ctx] per branch. */
+ORC_API uint64_t orc_exact_posterior_tree(const double *rates, uint64_t n, int n_nodes,
+                                          const uint32_t *parent, const uint32_t *subtree,
+                                          const double *blen, const uint8_t *root, const uint8_t *leaf,
+                                          uint64_t seed, uint64_t want, uint64_t max_trials, double *Jm,
+                                          double *Dm, double *J2, double *D2) {
+  orc_mt19937 g;
+  orc_mt_seed(&g, (uint32_t)seed);
+  const int B = n_nodes - 1;
+  orc_path *paths = (orc_path *)calloc((size_t)n_nodes * n, sizeof(orc_path));
+  uint8_t *seq = (uint8_t *)malloc((size_t)n_nodes * n);   /* end sequence of every node */
+  for (int i = 0; i < B * 8; ++i) { Jm[i] = Dm[i] = J2[i] = D2[i] = 0.0; }
+  double *J = (double *)malloc(sizeof(double) * (size_t)B * 8), *D = (double *)malloc(sizeof(double) * (size_t)B * 8);
+  uint64_t kept = 0;
+  for (uint64_t trial = 0; trial < max_trials && kept < want; ++trial) {
+    memcpy(seq, root, n);
+    int ok = 1;
+    for (int node = 1; node < n_nodes && ok; ++node) {
+      uint8_t *cur = seq + (size_t)node * n;
+      memcpy(cur, seq + (size_t)parent[node] * n, n);
+      orc_path *pp = paths + (size_t)node * n;
+      for (uint64_t s = 0; s < n; ++s) { pp[s].init = cur[s]; pp[s].n = 0; }
+      double t = 0.0;
+      for (;;) {
+        double total = 0.0;
+        for (uint64_t s = 1; s + 1 < n; ++s) total += rates[4 * cur[s - 1] + 2 * cur[s] + cur[s + 1]];
+        t += -log(1.0 - orc_mt_canonical(&g)) / total;
+        if (!(t < blen[node])) break;
+        double x = orc_mt_canonical(&g) * total;
+        uint64_t pick = n - 2;
+        for (uint64_t s = 1; s + 1 < n; ++s) {
+          const double r = rates[4 * cur[s - 1] + 2 * cur[s] + cur[s + 1]];
+          if (x < r) { pick = s; break; }
+          x -= r;
+        }
+        cur[pick] ^= 1;
+        path_push(&pp[pick], t);
+      }
+      if (subtree[node] == 1 && memcmp(cur, leaf + (size_t)node * n, n) != 0) ok = 0;
+    }
+    if (!ok) continue;
+    for (int i = 0; i < B * 8; ++i) { J[i] = 0.0; D[i] = 0.0; }
+    for (int node = 1; node < n_nodes; ++node) {
+      const orc_path *pp = paths + (size_t)node * n;
+      for (uint64_t s = 1; s + 1 < n; ++s)
+        add_suff_stats(&pp[s - 1], &pp[s], &pp[s + 1], blen[node], J + (node - 1) * 8, D + (node - 1) * 8);
+    }
+    for (int i = 0; i < B * 8; ++i) { Jm[i] += J[i]; Dm[i] += D[i]; J2[i] += J[i] * J[i]; D2[i] += D[i] * D[i]; }
+    ++kept;
+  }
+  for (int i = 0; i < B * 8 && kept; ++i) { Jm[i] /= kept; Dm[i] /= kept; J2[i] /= kept; D2[i] /= kept; }
+  for (size_t i = 0; i < (size_t)n_nodes * n; ++i) free(paths[i].t);
+  free(paths); free(seq); free(J); free(D);
+  return kept;
+}
+
 /* ------------------------------------------------- per-function KAT hooks */
 ORC_API void orc_kat_trans_prob_mat(int math_mode, double r0, double r1, double t, double *P) {
   orc_state st; st.math_mode = math_mode; set_math(&st);

@@ -91,3 +91,28 @@ def test_three_colour_schedule_is_a_valid_parallel_update():
                 o2.mh_site(s, 0)
     assert orc.paths_equal(o1.paths(), o2.paths())
     assert np.array_equal(o1.tri_llh(), o2.tri_llh())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,n", [("tree", 40000), ("pair", 12000), ("cat6", 10000)])
+def test_gpu_chain_matches_rung_a_chain_statistically(cfg, n):
+    """the same comparison with the GPU itself as the parallel chain: rung A is the reference's
+    chain (bit-identical to the linked library, tests/test_oracle_golden.py)"""
+    from epievo_amd.sampler import DeviceSampler
+    model, tree, fp = simulate(cfg, n, seed=13)
+    a = orc.Oracle(tree, model, fp, "A", seed=1)
+    a.reset()
+    JA, DA, _, accA = a.run_mcmc(4, 12)
+    d = DeviceSampler(0)
+    d.set_tree(tree)
+    d.set_model(model)
+    d.upload_paths(fp, 32)
+    d.reset()
+    JB, DB, nacc = d.run_mcmc(4, 12, 1)
+    accB = nacc / float(12 * (n - 2))
+    assert abs(accA - accB) < 0.01
+    sd = np.sqrt(np.maximum(JA, 1.0))
+    assert np.all(np.abs(JA - JB) < 6.0 * sd + 2.0)
+    B = tree.n_nodes - 1
+    np.testing.assert_allclose(DA.reshape(B, 8).sum(1), DB.reshape(B, 8).sum(1), rtol=1e-9)
+    assert np.all(np.abs(DA - DB) < 0.05 * DA.reshape(B, 8).sum(1, keepdims=True).repeat(8, 1).reshape(-1) + 1.0)
