@@ -46,7 +46,7 @@ def main():
             out.write("%s,%d,%.0f,%.0f,%.0f\n" % (k, n, bf, bw, bf + bw))
     tj = os.path.join(here, "traffic.json")
     data = json.load(open(tj)) if os.path.exists(tj) else {}
-    parts = [r for r in rows if r[0] in ("epv_mh_phase_kernel", "epv_mh_propose_kernel",
+    parts = [r for r in rows if r[0] in ("epv_mh_phase_kernel", "epv_mh_propose_kernel", "epv_mh_propose2_kernel",
                                          "epv_mh_jumps_kernel", "epv_mh_accept_kernel")]
     mh = ("+".join(r[0] for r in parts), parts[0][1], sum(r[2] for r in parts), sum(r[3] for r in parts))
     data[config] = {"kernel": mh[0], "round": tag,
