@@ -64,6 +64,8 @@ struct epv_ctx {
   uint64_t gpool2_cap = 0;
   double *d_segtab = nullptr;    // [B][4][6] single-segment matrices, refreshed by epv_reset
   uint32_t phase_parity = 0;     // accept lists are double-buffered by phase parity
+  int use_seg = -1;              // segment-parallel jump kernels (epv_jumps2.h): -1 = by workload
+                                 // (long branches, kbar >= 0.25), EPV_SEG_JUMPS=0/1 forces
   uint32_t tasks_per_wave = 0;   // epv_mh_jumps_kernel: lanes of a wave that own a task (0 = by workload)
   double kbar = 0.0;  // mean jumps per (site, branch) of the uploaded paths
   size_t mh_lds = 0;
@@ -109,6 +111,7 @@ struct DevTmp {
 void free_paths(epv_ctx *c) {
   dfree(c->S.meta); dfree(c->S.jumps); dfree(c->S.sel); dfree(c->S.tri);
   dfree(c->S.prop_llr); dfree(c->S.prop_flag); dfree(c->S.prop_states); dfree(c->S.tasks); dfree(c->S.alist);
+  dfree(c->S.segs); dfree(c->S.segout); dfree(c->S.btasks); dfree(c->S.bfirst);
   dfree(c->d_partial[0]); dfree(c->d_partial[1]);
   c->partial_cap[0] = c->partial_cap[1] = 0;
   c->have_paths = c->have_reset = false;
@@ -172,7 +175,7 @@ int plan_mh(epv_ctx *c) {
 // that uses them: level 0 holds one row per block, level 1 one row per 256 blocks
 // launch shape of epv_mh_propose2_kernel: per wave the constants, the matrix table, the node
 // table and a pool of doubles shared by the Felsenstein records (2 doubles) and the heavy-segment
-// records (8 doubles).  The pool covers the typical demand of 64 lanes with a margin (a wave that
+// records (EPV_HREC doubles).  The pool covers the typical demand of 64 lanes with a margin (a wave that
 // needs more runs in rounds) and always one lane's worst case.
 double p2_margin() {
   if (const char *e = std::getenv("EPV_P2_MARGIN")) { const double v = std::atof(e); if (v >= 1.0 && v <= 4.0) return v; }
@@ -184,17 +187,17 @@ int plan_p2(epv_ctx *c) {
                        (3u * (size_t)B * 64u * sizeof(epv_meta_t) + 15u) / 16u * 16u;   // constants, matrix table, node table, meta cache
   // one lane's worst case: every branch with 2C+1 segments (records K+1, heavy K)
   const uint64_t worst_rec = (uint64_t)B * (2u * C + 2u), worst_heavy = (uint64_t)B * (2u * C + 1u);
-  const uint64_t worst_dbl = 2u * worst_rec + 8u * worst_heavy;
+  const uint64_t worst_dbl = 2u * worst_rec + EPV_HREC * worst_heavy;
   // typical: K = 1 + Poisson(2 kbar) segments per branch; heavy segments E[K; K >= 2]
   const double lam = 2.0 * c->kbar;
   const double heavy_per_branch = (1.0 + lam) - std::exp(-lam);
   uint32_t n_internal = 0;
   for (uint32_t node = 1; node < N; ++node) n_internal += c->subtree[node] != 1u;
   const double rec_per_lane = B * (1.0 + lam) + n_internal;     // K per branch, +1 for an internal node's q
-  const uint64_t typical_dbl = (uint64_t)(64.0 * (2.0 * rec_per_lane + 8.0 * B * heavy_per_branch) * p2_margin()) + 64u;
+  const uint64_t typical_dbl = (uint64_t)(64.0 * (2.0 * rec_per_lane + (double)EPV_HREC * B * heavy_per_branch) * p2_margin()) + 64u;
   const uint64_t max_fit = fixed + 64u < 160u * 1024u ? (160u * 1024u - fixed) / 8u : 0u;
   const uint64_t want = std::max(worst_dbl, typical_dbl);
-  const bool lds_ok = want <= max_fit && (fixed + want * 8u) * 8u <= 160u * 1024u;   // >= 8 waves per CU
+  const bool lds_ok = want <= max_fit && (fixed + want * 8u) * 5u <= 160u * 1024u;   // >= 5 waves per CU
   const bool use_lds = std::getenv("EPV_FORCE_GLOBAL_POOL") ? false
                        : std::getenv("EPV_FORCE_LDS_POOL") ? want <= max_fit : lds_ok;
   if (fixed > 150u * 1024u) return fail(c, EPV_ERR_ARG, "tree too large for the 160 KiB LDS node table");
@@ -209,7 +212,7 @@ int plan_p2(epv_ctx *c) {
   const uint64_t rows = worst_rec;
   const uint64_t list_cap = std::max<uint64_t>(worst_heavy, (uint64_t)(64.0 * B * heavy_per_branch * 2.0) + 64u);
   const uint64_t blocks = (c->S.phase_cap + 63u) / 64u;
-  const uint64_t need = blocks * (rows * 128u + list_cap * 8u);
+  const uint64_t need = blocks * (rows * 128u + list_cap * EPV_HREC);
   if (need > c->gpool2_cap) {
     dfree(c->d_gpool2);
     c->gpool2_cap = 0;
@@ -320,16 +323,23 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   static const bool p2_global = std::getenv("EPV_PROPOSE_V2_GLOBAL") != nullptr;
   const bool p2 = c->use_p2 && !refq && (!c->p2_gpool || p2_global);
   uint32_t list_mode = 0;
+  // segment-parallel jumps pay on long branches (single branch T = 1: +17 %, every segment is
+  // dirty and needs several trials) and cost on short ones (tree.nwk: -12 %, one dirty segment in
+  // fourteen branches does not repay the extra hand-over): profiles/r02_ab_seg_jumps.txt
+  const bool seg_on = c->use_seg < 0 ? c->kbar >= 0.25 : c->use_seg != 0;
+  const uint32_t seg_mode = (p2 && seg_on) ? 1u : 0u;
   if (p2) {
     list_mode = 1u + (c->phase_parity & 1u);
     if (c->p2_gpool)
       hipLaunchKernelGGL(epv_mh_propose2_kernel<true>, dim3((unsigned)blocks), dim3(64), c->p2_lds, c->stream, c->S,
                          (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
-                         c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, c->d_gpool2, c->d_segtab);
+                         c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, c->d_gpool2, c->d_segtab,
+                         seg_mode);
     else
       hipLaunchKernelGGL(epv_mh_propose2_kernel<false>, dim3((unsigned)blocks), dim3(64), c->p2_lds, c->stream, c->S,
                          (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
-                         c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, (double *)nullptr, c->d_segtab);
+                         c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, (double *)nullptr, c->d_segtab,
+                         seg_mode);
     ++c->phase_parity;
   } else {
     auto kern = c->mh_gpool ? (refq ? epv_mh_propose_kernel<true, true> : epv_mh_propose_kernel<true, false>)
@@ -338,7 +348,20 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
                        (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last,
                        c->pool_entries, c->d_counters, c->mh_gpool ? c->d_gpool : (double *)nullptr);
   }
-  {
+  if (seg_mode) {
+    // dirty segments one lane each, then their branches one lane each; both lists are sized on
+    // the device, the grids cover a quarter / an eighth of the capacity and stride over the rest
+    const unsigned sx = (unsigned)std::min<uint64_t>(32u, std::max<uint64_t>(1u, (c->S.seg_cap / 4u + 255u) / 256u));
+    const unsigned bx = (unsigned)std::min<uint64_t>(16u, std::max<uint64_t>(1u, (c->S.btask_cap / 8u + 255u) / 256u));
+    hipLaunchKernelGGL(epv_seg_search_kernel, dim3(sx, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N), c->stream,
+                       c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, c->d_counters);
+    hipLaunchKernelGGL(epv_seg_assemble_kernel, dim3(bx, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N), c->stream,
+                       c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, s0, c->d_counters);
+    // the sequential kernel behind them with a minimal grid: branches of more than 64 segments
+    // and whatever did not fit the lists (normally nothing: it reads empty lists and leaves)
+    hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3(1, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N), c->stream, c->S,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), sweep, 32u, s0, 0.0, 0.0, c->d_counters);
+  } else {
     // one lane per dirty (site, branch) pair; the count is only known on the device, so
     // launch a grid that covers the typical case and grid-stride over the rest
     const uint64_t max_tasks = blocks / EPV_SHARDS * 64u * c->S.B + 64u * c->S.B;  // per shard
@@ -415,6 +438,7 @@ EPV_API epv_ctx *epv_create(int device_id) {
   epv_ctx *c = new epv_ctx();
   c->device = device_id;
   if (const char *e = std::getenv("EPV_PROPOSE_V1")) c->use_p2 = std::atoi(e) == 0;
+  if (const char *e = std::getenv("EPV_SEG_JUMPS")) c->use_seg = std::atoi(e) != 0 ? 1 : 0;
   if (const char *e = std::getenv("EPV_TASKS_PER_WAVE")) {  // tuning knob
     const int v = std::atoi(e);
     if (v >= 1 && v <= 64) c->tasks_per_wave = (uint32_t)v;
@@ -546,6 +570,18 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   // one task region per counter shard, sized for the worst case of the blocks that use it
   c->S.task_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u * B;
   HIP_TRY(c, hipMalloc(&c->S.tasks, c->S.task_cap * EPV_SHARDS * 2u * sizeof(unsigned long long)));
+  // segment-parallel jump sampling: branch list as large as the task regions, segment list for
+  // the expected number of dirty segments with a wide margin (what does not fit falls back to the
+  // sequential kernel's lists)
+  {
+    const double kb = E ? (double)offsets[E] / (double)E : 0.0;
+    c->S.btask_cap = c->S.task_cap;
+    c->S.seg_cap = (uint64_t)((double)c->S.task_cap * std::min(8.0, std::max(0.5, 0.5 + 3.0 * kb))) + 256u;
+    HIP_TRY(c, hipMalloc(&c->S.segs, c->S.seg_cap * EPV_SHARDS * sizeof(EpvSegTask)));
+    HIP_TRY(c, hipMalloc(&c->S.segout, c->S.seg_cap * EPV_SHARDS * sizeof(EpvSegOut)));
+    HIP_TRY(c, hipMalloc(&c->S.btasks, c->S.btask_cap * EPV_SHARDS * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc(&c->S.bfirst, c->S.btask_cap * EPV_SHARDS * sizeof(uint32_t)));
+  }
   // accept list: one region per counter shard, room for every site of the blocks that use it
   c->S.alist_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u;
   HIP_TRY(c, hipMalloc(&c->S.alist, c->S.alist_cap * EPV_SHARDS * sizeof(uint32_t)));

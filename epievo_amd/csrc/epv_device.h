@@ -34,6 +34,20 @@ struct EpvModelConst {  // staged into LDS by every block
   double T[4];
 };
 
+struct EpvSegTask {      // one dirty segment of a proposal: sample its jump times
+  unsigned long long w0; // site | node << 40 | segment index << 52
+  double len;            // segment length (< 0: blank entry)
+  double start;          // time of the segment's start on the branch
+  unsigned long long w3; // start state | end state << 1 | trip0 << 2
+};
+struct EpvSegOut {       // what the search found
+  uint32_t cnt;          // jumps of the winning trial
+  uint32_t tstar;        // the winning trial
+  uint32_t maxm;         // most jumps any trial up to the winner made (capacity check)
+  uint32_t pad;
+  double j0, j1;         // its first two jump times, absolute on the branch
+};
+
 struct EpvDev {
   uint64_t n;        // local sites
   uint64_t g0;       // global index of local site 0
@@ -57,6 +71,13 @@ struct EpvDev {
   uint32_t *alist;     // [EPV_SHARDS][alist_cap] phase-local ids of the sites whose proposal differs
                        // from their current path (the accept kernel's work list)
   uint64_t alist_cap;
+  // segment-parallel jump sampling (epv_jumps2.h): per counter shard a list of dirty segments,
+  // the results of their searches, and a list of the branches they belong to
+  struct EpvSegTask *segs;     // [EPV_SHARDS][seg_cap]
+  struct EpvSegOut *segout;    // [EPV_SHARDS][seg_cap]
+  unsigned long long *btasks;  // [EPV_SHARDS][btask_cap] site | branch << 40 | dirty segments << 52 | end state << 59
+  uint32_t *bfirst;            // [EPV_SHARDS][btask_cap] index of the branch's first dirty segment
+  uint64_t seg_cap, btask_cap;
   uint32_t W;        // 64-bit words per (site, branch) in prop_states = ceil((2C+1)/64)
   uint32_t flags;    // EPV_OPT_* (epv_set_options)
   const EpvModelConst *model;  // device copy
@@ -80,7 +101,8 @@ struct EpvIndepConst {
 // counters[] slots
 enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_TASKS2 = 4,
        EPV_CNT_ALIST0 = 5, EPV_CNT_ALIST1 = 6,   // accept-list lengths, double-buffered by phase parity
-       EPV_CNT_N = 7 };
+       EPV_CNT_SEG = 7,                          // dirty segments (low word) and their branches (high word)
+       EPV_CNT_N = 8 };
 // Every counter is sharded 64 ways with a 128-byte stride (one device-scope atomic word
 // saturates near 90 ops/us; 5000 waves hitting ONE word would serialise for ~60 us).
 // A block uses shard (blockIdx.x & 63); the host sums the shards.

@@ -293,7 +293,11 @@ __device__ __forceinline__ int scan_trials(uint32_t seed_lo, uint32_t seed_hi, u
                                            uint32_t W, uint32_t a0, uint32_t end, double T, double r0,
                                            double r1, double trunc, uint32_t room, double *dst,
                                            uint64_t stride, uint32_t max_store, double start_time,
-                                           uint32_t &t_out, uint32_t &nj_out, bool nielsen = true) {
+                                           uint32_t &t_out, uint32_t &nj_out, bool nielsen = true,
+                                           uint32_t *maxm = nullptr) {
+  // maxm (optional): running maximum of the jumps made by the trials evaluated here, failed ones
+  // included (a trial classified "no jump" makes none) -- what decides a capacity overflow when
+  // the room left in the path is only known later (epv_jumps2.h)
   // flip: the segment changes state AND is sampled by Nielsen's method (forward-rejection mode,
   // EPV_FLAG_FORWARD_REJECTION, treats such a segment like any other: a trial must END in `end`)
   const bool flip = nielsen && a0 != end;
@@ -330,6 +334,7 @@ __device__ __forceinline__ int scan_trials(uint32_t seed_lo, uint32_t seed_hi, u
     const double nb = flip ? bound : 0.0;
     const int oc = run_trial(seed_lo, seed_hi, gsite, sweep, node, k, t, u, a0, end, T, r0, r1, nb, nb,
                              trunc, room, dst, stride, max_store, start_time, nj_out, nielsen);
+    if (maxm && nj_out > *maxm) *maxm = nj_out;
     if (oc != TRIAL_FAIL) { t_out = t; return oc; }
     ++t;
   }
@@ -860,6 +865,8 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
   }
 }
 
+#include "epv_jumps2.h"
+
 // =========================================================================
 //  acceptance (log_accept_rate SingleSiteSampler.cpp:396-433, Metropolis_Hastings_site
 //  :510-533): one lane per site of the colour, after epv_mh_propose_kernel has written
@@ -960,6 +967,8 @@ __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
     counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)] = 0ull;
     counters[EPV_CNT_IDX(EPV_CNT_TASKS2, threadIdx.x)] = 0ull;
     if (list_mode) counters[EPV_CNT_IDX(list_mode == 2u ? EPV_CNT_ALIST0 : EPV_CNT_ALIST1, threadIdx.x)] = 0ull;
+    counters[EPV_CNT_IDX(EPV_CNT_COOP, threadIdx.x)] += counters[EPV_CNT_IDX(EPV_CNT_SEG, threadIdx.x)] >> 32;
+    counters[EPV_CNT_IDX(EPV_CNT_SEG, threadIdx.x)] = 0ull;
   }
 }
 

@@ -36,8 +36,11 @@ struct EpvSegRec {      // one segment, everything the recursions need
   double PT00, PT10;    // get_trans_prob(len, prev, 0) for prev = 0, 1 (h = exp(-len (r0 + r1)))
   double nb0, nb1;      // no-jump bounds of trial 1 for a segment that waits in state 0 / 1
   double u_end, u_first;  // the segment's Philox block: end-state uniform, trial 1's first draw
+  double len;           // segment length (kept for the jump tasks)
+  uint64_t info;        // trip0 | owner lane << 3 | node << 9 | k << 21
 };
 #define EPV_SEGTAB_DBL 6u   /* table entry = the first six fields */
+#define EPV_HREC 10u        /* doubles per heavy-segment record: the eight fields, length, address word */
 
 __device__ __forceinline__ void epv_seg_matrices(double len, double r0, double r1, double out[6]) {
   const double denom = r0 + r1;
@@ -112,7 +115,9 @@ template <bool GPOOL>
 __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first,
     uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t pool_dbl, uint32_t list_cap,
-    uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab) {
+    uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab, uint32_t seg_mode) {
+  // seg_mode: 1 = dirty SEGMENTS go to the segment-parallel jump kernels (epv_jumps2.h); 0 = dirty
+  // branches go to epv_mh_jumps_kernel's bucketed lists
   // pool_dbl: LDS pool -- doubles per wave; GPOOL -- record ROWS per lane (list_cap heavy records
   // behind them; unused for the LDS pool, where records and list share pool_dbl)
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
   const int lane = epv_lane();
   // GPOOL: rows of 64 interleaved records (row r of lane l at (r * 64 + l) * 2 doubles), then
   // the flat heavy list; LDS: records packed by a wave prefix sum, the heavy list behind them
-  double *pool = GPOOL ? gpool + (size_t)blockIdx.x * ((size_t)pool_dbl * 128u + (size_t)list_cap * 8u)
+  double *pool = GPOOL ? gpool + (size_t)blockIdx.x * ((size_t)pool_dbl * 128u + (size_t)list_cap * EPV_HREC)
                        : s_mem + const_dbl + tab_dbl + regA_dbl + mc_dbl;
   for (uint32_t i = threadIdx.x; i < tab_dbl; i += blockDim.x) s_tab[i] = segtab[i];
   stage_constants(S, s_const);
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
     const uint32_t inclR = wave_incl_scan_u32(wantR), inclH = wave_incl_scan_u32(wantH);
     // non-decreasing in the lane index, so the lanes that run are a prefix of the pending ones
     const bool run = pending && (GPOOL ? (need_rec <= pool_dbl && inclH <= list_cap)
-                                       : (2u * inclR + 8u * inclH <= pool_dbl));
+                                       : (2u * inclR + EPV_HREC * inclH <= pool_dbl));
     const unsigned long long rmask = __ballot(run);
     const int hi_lane = rmask ? 63 - __clzll((long long)rmask) : 0;
     const uint32_t totR = rmask ? __shfl(inclR, hi_lane) : 0u, totH = rmask ? __shfl(inclH, hi_lane) : 0u;
@@ -198,9 +203,9 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
           const bool last_seg = (k + 1u == K);
           const bool take_left = tl < tr;
           const double seg_end = last_seg ? s_blen[node] : (take_left ? tl : tr);
-          double *rec = list + (size_t)(hcur + k) * 8u;
-          rec[0] = seg_end - seg_start;
-          rec[1] = epv_u2d((uint64_t)trip0 | ((uint64_t)lane << 3) | ((uint64_t)node << 9) | ((uint64_t)k << 21));
+          double *rec = list + (size_t)(hcur + k) * EPV_HREC;
+          rec[8] = seg_end - seg_start;
+          rec[9] = epv_u2d((uint64_t)trip0 | ((uint64_t)lane << 3) | ((uint64_t)node << 9) | ((uint64_t)k << 21));
           if (!last_seg) {
             if (take_left) { trip0 ^= 4u; ++i; tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF; }
             else { trip0 ^= 1u; ++j; tr = j < R.nj ? R.j[(uint64_t)j * n] : EPV_INF; }
@@ -215,9 +220,9 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
 
     // ---- 2. evaluate them densely, one segment per lane
     for (uint32_t i = (uint32_t)lane; i < totH; i += 64u) {
-      double *rec = list + (size_t)i * 8u;
-      const double len = rec[0];
-      const uint64_t info = epv_d2u(rec[1]);
+      double *rec = list + (size_t)i * EPV_HREC;
+      const double len = rec[8];
+      const uint64_t info = epv_d2u(rec[9]);
       const uint32_t trip0 = (uint32_t)info & 7u, owner = (uint32_t)(info >> 3) & 63u;
       const uint32_t node = (uint32_t)(info >> 9) & 4095u, k = (uint32_t)(info >> 21);
       double m[6];
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
         } else {
           hcur -= K;
           for (uint32_t kk = K; kk-- > 0u;) {
-            const double *hr = list + (size_t)(hcur + kk) * 8u;
+            const double *hr = list + (size_t)(hcur + kk) * EPV_HREC;
             const double P00 = hr[0], P11 = hr[1];
             const double P01 = 1.0 - P00, P10 = 1.0 - P11;
             const double a = P00 * n0 + P01 * n1;
@@ -288,6 +293,10 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
     uint32_t hcur = hbase;
     for (uint32_t node = 1u; node < S.N; ++node) {
       const uint32_t b = node - 1u;
+      // what the wave-wide hand-over below needs from this lane's branch
+      uint32_t nds = 0, Kb = 0, st_b = 0, end_b = 0, hrec0 = 0, trip_b = 0;
+      unsigned long long w64 = 0ull;
+      bool dirty_b = false;
       if (run) {
         const uint32_t mL = s_meta[(0u * B + b) * 64u + lane], mR = s_meta[(1u * B + b) * 64u + lane];
         const uint32_t K = (mL & EPV_NJ_MASK) + (mR & EPV_NJ_MASK) + 1u;
@@ -320,30 +329,100 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
             const epv_block2 blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, 0u, 0u, 0u);
             u_end = blk.d0; u_first = blk.d1;
           } else {
-            const double *hr = list + (size_t)(hcur + k) * 8u;
+            const double *hr = list + (size_t)(hcur + k) * EPV_HREC;
             PT0 = prev ? hr[3] : hr[2];
             nb = prev ? hr[5] : hr[4];
             u_end = hr[6]; u_first = hr[7];
           }
           const double p0 = PT0 * nxt0 / (prev ? pk1 : pk0);
           const uint32_t sampled = (u_end > p0) ? 1u : 0u;
-          // trial 1's first draw is the other half of the same Philox block
-          clean = clean && (sampled == prev) && (1.0 - u_first < nb);
+          // trial 1's first draw is the other half of the same Philox block: a segment that keeps
+          // its state and provably has no jump in trial 1 is clean
+          const bool seg_clean = (sampled == prev) && (1.0 - u_first < nb);
+          clean = clean && seg_clean;
+          nds += seg_clean ? 0u : 1u;
           word |= (unsigned long long)sampled << (k & 63u);
+          if (k < 64u) w64 = word;
           if ((k & 63u) == 63u) { states[k >> 6] = word; word = 0ull; }
           prev = sampled;
           pk0 = nxt0; pk1 = nxt1;
         }
+        hrec0 = hcur;
         if (K >= 2u) hcur += K;
         if ((K & 63u) && !clean) states[(K - 1u) >> 6] = word;   // only a dirty branch is read back
         regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children
         // same as the current path?  (no jumps on either, same start state)
         ident = ident && clean && mM == (start_state << EPV_INIT_SHIFT);
-        if (!clean) {
-          dirty |= 1ull << (b & 63u);
-          if (K == 2u || K >= 4u) multi |= 1ull << (b & 63u);   // four buckets by segment count
-          if (K >= 3u) deep |= 1ull << (b & 63u);
+        dirty_b = !clean;
+        Kb = K; st_b = start_state; end_b = prev;
+        trip_b = 4u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT);
+      }
+      bool old_list = dirty_b;
+      if (seg_mode) {
+        // ---- dirty SEGMENTS onto the segment list (one lane each in epv_seg_search_kernel) and the
+        //      branch onto the assemble list: one atomic per wave and node reserves both ranges.
+        //      A branch with more than 64 segments, or one that finds the lists full, takes the
+        //      bucketed lists of the sequential kernel instead.
+        const bool cand = dirty_b && Kb <= 64u;
+        const uint32_t wS = cand ? nds : 0u, wB = cand ? 1u : 0u;
+        const uint32_t inclS = wave_incl_scan_u32(wS), inclB = wave_incl_scan_u32(wB);
+        const uint32_t totS = __shfl(inclS, 63), totB = __shfl(inclB, 63);
+        if (totB) {
+          const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+          unsigned long long base = 0ull;
+          if (lane == 0)
+            base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_SEG, shard)],
+                             (unsigned long long)totS | ((unsigned long long)totB << 32));
+          const uint32_t bS = __shfl((uint32_t)base, 0), bB = __shfl((uint32_t)(base >> 32), 0);
+          if (cand) {
+            const uint64_t i0 = (uint64_t)bS + (inclS - wS), j0 = (uint64_t)bB + (inclB - 1u);
+            EpvSegTask *segs = S.segs + (uint64_t)shard * S.seg_cap;
+            if (i0 + nds <= S.seg_cap && j0 < S.btask_cap) {
+              S.btasks[(uint64_t)shard * S.btask_cap + j0] =
+                  site | ((unsigned long long)b << 40) | ((unsigned long long)nds << 52) | ((unsigned long long)end_b << 59);
+              S.bfirst[(uint64_t)shard * S.btask_cap + j0] = (uint32_t)i0;
+              uint32_t prev = st_b;
+              double tp = 0.0;     // running sum of the segment lengths (SingleSiteSampler.cpp:218)
+              uint64_t at = i0;
+              for (uint32_t k = 0; k < Kb; ++k) {
+                const uint32_t sampled = (uint32_t)(w64 >> k) & 1u;
+                double len;
+                uint32_t trip0;
+                bool seg_clean;
+                if (Kb == 1u) {
+                  len = s_blen[node];
+                  trip0 = trip_b;
+                  seg_clean = false;       // the only segment of a dirty branch
+                } else {
+                  const double *hr = list + (size_t)(hrec0 + k) * EPV_HREC;
+                  len = hr[8];
+                  trip0 = (uint32_t)epv_d2u(hr[9]) & 7u;
+                  seg_clean = (sampled == prev) && (1.0 - hr[7] < (prev ? hr[5] : hr[4]));
+                }
+                if (!seg_clean) {
+                  EpvSegTask t;
+                  t.w0 = site | ((unsigned long long)node << 40) | ((unsigned long long)k << 52);
+                  t.len = len;
+                  t.start = tp;
+                  t.w3 = prev | (sampled << 1) | (trip0 << 2);
+                  segs[at++] = t;
+                }
+                tp += len;
+                prev = sampled;
+              }
+              old_list = false;
+            } else {
+              // no room: blank what this lane reserved inside the lists, fall back
+              for (uint64_t i = i0; i < i0 + nds && i < S.seg_cap; ++i) segs[i].len = -1.0;
+              if (j0 < S.btask_cap) S.btasks[(uint64_t)shard * S.btask_cap + j0] = ~0ull;
+            }
+          }
         }
+      }
+      if (old_list) {
+        dirty |= 1ull << (b & 63u);
+        if (Kb == 2u || Kb >= 4u) multi |= 1ull << (b & 63u);   // four buckets by segment count
+        if (Kb >= 3u) deep |= 1ull << (b & 63u);
       }
       if ((b & 63u) == 63u || node + 1u == S.N) {
         epv_flush_tasks(S, counters, dirty, multi, deep, b, site, lane);

@@ -244,3 +244,49 @@ def test_long_branch_beyond_127_jumps(T, n):
     for w in range(3):
         g.sweep(1, 41, sweep_base=w)
     assert g.capacity() > maxj and g.capacity_events
+
+
+@pytest.mark.parametrize("cfg,n,env", [("tree", 20011, {"EPV_SEG_JUMPS": "1"}), ("pair", 9000, {"EPV_SEG_JUMPS": "0"}),
+                                       ("pair", 9000, {"EPV_SEG_JUMPS": "1"}), ("cat6", 3000, {"EPV_SEG_JUMPS": "1"}),
+                                       ("tree", 20011, {"EPV_PROPOSE_V1": "1"}), ("pair", 9000, {"EPV_PROPOSE_V1": "1"}),
+                                       ("bal16", 2000, {"EPV_PROPOSE_V2_GLOBAL": "1", "EPV_FORCE_GLOBAL_POOL": "1"}),
+                                       ("tree", 5000, {"EPV_FORCE_GLOBAL_POOL": "1", "EPV_PROPOSE_V2_GLOBAL": "1",
+                                                       "EPV_SEG_JUMPS": "1"})])
+def test_every_kernel_path_is_bit_exact(cfg, n, env):
+    """the library picks its kernels by workload (proposal kernel generation, where its record
+    pool lives, sequential or segment-parallel jump sampling); every combination must give the
+    oracle's bits, so each is forced here on a workload that would not select it by itself"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import orc
+from common import simulate
+from epievo_amd.sampler import DeviceSampler
+model, tree, fp = simulate(%r, %d, seed=6)
+cap = int(max(16, 2 * fp.counts().max() + 8))
+d = DeviceSampler(0); d.set_tree(tree); d.set_model(model); d.upload_paths(fp, cap); d.reset()
+o = orc.Oracle(tree, model, fp, "B", cap=cap, seed=19); o.reset()
+Jd, Dd, nd = d.run_mcmc(2, 3, 19, sweep_base=4)
+Jo, Do, no, _ = o.run_mcmc(2, 3, sweep_base=4)
+assert nd == no and np.array_equal(Jd, Jo) and np.array_equal(Dd, Do)
+assert orc.paths_equal(d.paths(), o.paths()) and np.array_equal(d.tri_llh(), o.tri_llh())
+# a tiny capacity: the overflow decisions must be the sequential sampler's too
+cap2 = int(fp.counts().max())
+d2 = DeviceSampler(0); d2.set_tree(tree); d2.set_model(model); d2.upload_paths(fp, cap2); d2.reset()
+o2 = orc.Oracle(tree, model, fp, "B", cap=cap2, seed=23); o2.reset()
+for w in range(2):
+    try:
+        na = d2.sweep(1, 23, sweep_base=w)
+    except Exception as e:
+        na = None
+    nb = o2.sweep(w)
+    assert orc.paths_equal(d2.paths(), o2.paths())
+assert d2.counters()["overflow"] == o2.counters()["overflow"]
+print("ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), cfg, n)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
