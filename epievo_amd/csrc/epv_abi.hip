@@ -378,18 +378,23 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
                        c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, 0.0, 0.0, c->d_counters);
   }
+  // meta cache of the accept kernel: 5 columns x B words per lane in LDS while that stays small
+  // (B <= 8: 20 KB per block next to the 24 KB of accumulators)
+  static const bool no_cache = std::getenv("EPV_ACCEPT_NO_CACHE") != nullptr;
+  const uint32_t meta_cache = (c->S.B <= 8u && !no_cache) ? 1u : 0u;
+  const size_t acc_lds = const_lds_bytes(c->S.N) + (meta_cache ? (size_t)5u * c->S.B * 256u * sizeof(epv_meta_t) : 0u);
   if (list_mode) {
     // the listed sites (proposal differs from the current path) per shard: typically ~30 % of the
     // colour; the grid covers half of the worst case and strides over the rest
     const uint64_t per_shard = (threads + EPV_SHARDS - 1u) / EPV_SHARDS;
     const unsigned ax = (unsigned)std::max<uint64_t>(1u, (per_shard / 2u + 255u) / 256u);
-    hipLaunchKernelGGL(epv_mh_accept_kernel, dim3(ax, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N), c->stream,
+    hipLaunchKernelGGL(epv_mh_accept_kernel, dim3(ax, EPV_SHARDS), dim3(256), acc_lds, c->stream,
                        c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo,
-                       own_hi, c->d_counters, list_mode);
+                       own_hi, c->d_counters, list_mode, meta_cache);
   } else {
     hipLaunchKernelGGL(epv_mh_accept_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256),
-                       const_lds_bytes(c->S.N), c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->d_counters, 0u);
+                       acc_lds, c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->d_counters, 0u, meta_cache);
   }
   if (c->timing) HIP_TRY(c, hipEventRecord(e1, c->stream));
   HIP_TRY(c, hipGetLastError());

@@ -200,6 +200,36 @@ __device__ __forceinline__ double triple_llh(const EpvDev &S, const double *s_mo
   return llh;
 }
 
+// the same with the meta words of the three columns already in LDS (mc[(col * B + b) * stride],
+// col = the column's index in the caller's cache): the accept kernel fetches the 5 B words a
+// site needs in ONE batch of independent loads instead of paying a dependent global round trip
+// per branch and triple (it is bound by memory latency: SQ_WAIT_ANY was 70 % of its wave cycles)
+template <class ACC>
+__device__ __forceinline__ double triple_llh_cached(const EpvDev &S, const double *s_model,
+                                                    const double *s_blen, const epv_meta_t *mc, uint32_t stride,
+                                                    uint32_t cl, uint32_t bl, uint64_t sl, uint32_t cm, uint32_t bm,
+                                                    uint64_t sm, uint32_t cr, uint32_t br, uint64_t sr, ACC &A) {
+  acc_clear(A);
+  uint32_t rl = 0, rm = 0, rr = 0;
+  const uint32_t B = S.B;
+  for (uint32_t b = 0; b < B; ++b) {
+    const uint32_t ml = mc[(cl * B + b) * stride], mm = mc[(cm * B + b) * stride], mr = mc[(cr * B + b) * stride];
+    PathRef L, M, R;
+    L.j = S.jumps + ((uint64_t)bl * B + b) * S.C * S.n + sl; L.nj = ml & EPV_NJ_MASK; L.init = ml >> EPV_INIT_SHIFT;
+    M.j = S.jumps + ((uint64_t)bm * B + b) * S.C * S.n + sm; M.nj = mm & EPV_NJ_MASK; M.init = mm >> EPV_INIT_SHIFT;
+    R.j = S.jumps + ((uint64_t)br * B + b) * S.C * S.n + sr; R.nj = mr & EPV_NJ_MASK; R.init = mr >> EPV_INIT_SHIFT;
+    if (b == 0) { rl = L.init; rm = M.init; rr = R.init; }
+    merge3(L, M, R, S.n, s_blen[b + 1], A);
+  }
+  const double *rates = s_model, *lrates = s_model + 8, *T = s_model + 16;
+  double llh = T[2 * rl + rm] * T[2 * rm + rr];
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) s += (double)acc_j(A, c) * lrates[c] - acc_d(A, c) * rates[c];
+  llh += s;
+  return llh;
+}
+
 // ------------------------------------------------ forward rejection trial
 enum { TRIAL_FAIL = 0, TRIAL_OK = 1, TRIAL_OVERFLOW = 2 };
 
@@ -882,12 +912,15 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
 __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
     uint64_t first, uint64_t last, uint64_t own_first, uint64_t own_last,
-    unsigned long long *counters, uint32_t list_mode) {
+    unsigned long long *counters, uint32_t list_mode, uint32_t meta_cache) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   __shared__ double s_accd[8 * 256];
   __shared__ uint32_t s_accj[8 * 256];
   stage_constants(S, s_mem);
   const double *s_const = s_mem, *s_blen = s_mem + 20;
+  // meta cache [5 columns][B][256 lanes] behind the constants when the launch provided room for
+  // it (meta_cache != 0: small trees); column 2 = the proposal
+  epv_meta_t *s_mc = reinterpret_cast<epv_meta_t *>(s_mem + ((20u + S.N + 1u) & ~1u)) + threadIdx.x;
   const int lane = epv_lane();
   AccLds A;
   A.d = s_accd + threadIdx.x; A.j = s_accj + threadIdx.x; A.stride = 256u;
@@ -924,15 +957,36 @@ __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
       // for this site's column (one loop, so merge3 is instantiated once)
       const uint32_t selP = selM ^ 1u;
       const uint64_t g = S.g0 + site;
-      const uint32_t selLL = (g > 1u) ? S.sel[site - 2] : 0u;
-      const uint32_t selRR = (g < S.n_global - 2u) ? S.sel[site + 2] : 0u;
+      const bool hasLL = g > 1u, hasRR = g < S.n_global - 2u;
+      const uint32_t selLL = hasLL ? S.sel[site - 2] : 0u;
+      const uint32_t selRR = hasRR ? S.sel[site + 2] : 0u;
+      if (meta_cache) {
+        // all the meta words of the five columns in one batch of independent loads
+        const uint32_t B = S.B;
+#pragma unroll 4
+        for (uint32_t b = 0; b < B; ++b) {
+          const epv_meta_t m0 = hasLL ? S.meta[meta_idx(S, selLL, b, site - 2)] : (epv_meta_t)0;
+          const epv_meta_t m1 = S.meta[meta_idx(S, selL, b, site - 1)];
+          const epv_meta_t m2 = S.meta[meta_idx(S, selP, b, site)];
+          const epv_meta_t m3 = S.meta[meta_idx(S, selR, b, site + 1)];
+          const epv_meta_t m4 = hasRR ? S.meta[meta_idx(S, selRR, b, site + 2)] : (epv_meta_t)0;
+          s_mc[(0u * B + b) * 256u] = m0;
+          s_mc[(1u * B + b) * 256u] = m1;
+          s_mc[(2u * B + b) * 256u] = m2;
+          s_mc[(3u * B + b) * 256u] = m3;
+          s_mc[(4u * B + b) * 256u] = m4;
+        }
+      }
       for (int w = 0; w < 3; ++w) {
-        if ((w == 0 && !(g > 1u)) || (w == 2 && !(g < S.n_global - 2u))) continue;
+        if ((w == 0 && !hasLL) || (w == 2 && !hasRR)) continue;
         const uint64_t c = site - 1u + (uint64_t)w;
         const uint32_t bl = (w == 0) ? selLL : (w == 1) ? selL : selP;
         const uint32_t bm = (w == 0) ? selL : (w == 1) ? selP : selR;
         const uint32_t br = (w == 0) ? selP : (w == 1) ? selR : selRR;
-        const double v = triple_llh(S, s_const, s_blen, bl, c - 1u, bm, c, br, c + 1u, A);
+        const double v = meta_cache
+                             ? triple_llh_cached(S, s_const, s_blen, s_mc, 256u, (uint32_t)w, bl, c - 1u, (uint32_t)w + 1u,
+                                                 bm, c, (uint32_t)w + 2u, br, c + 1u, A)
+                             : triple_llh(S, s_const, s_blen, bl, c - 1u, bm, c, br, c + 1u, A);
         if (w == 0) llh_l = v; else if (w == 1) llh_m = v; else llh_r = v;
       }
     }

@@ -1,0 +1,25 @@
+"""RCCL on the one GPU of the test box: the nccl (= RCCL) process group of torch.distributed with
+the library's device buffers -- zero-copy views through the CUDA array interface, an in-place
+all-gather, a send/receive pair, and ShardedSampler over TorchComm equal to the plain device call
+(tools/nccl_selfcheck.py, launched through torch.distributed.run as bench.py is).  More than one
+rank needs more than one GPU: that leg is only covered by the gloo tests (tests/test_sharded.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_selfcheck():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tools", "nccl_selfcheck.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "nccl selfcheck ok: world 1" in r.stdout
