@@ -58,6 +58,7 @@ struct epv_ctx {
   // second-generation proposal kernel (epv_propose2.h)
   bool use_p2 = true;            // EPV_PROPOSE_V1=1 falls back to the first kernel (A/B runs)
   uint32_t p2_pool = 0, p2_list_cap = 0;   // LDS: doubles per wave; global slab: rows per lane + heavy records
+  uint32_t p2_waves = 1;                   // waves per block
   bool p2_gpool = false;
   size_t p2_lds = 0;
   double *d_gpool2 = nullptr;
@@ -183,8 +184,10 @@ double p2_margin() {
 }
 int plan_p2(epv_ctx *c) {
   const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
-  const size_t fixed = const_lds_bytes(N) + (size_t)B * 4u * 6u * 8u + ((((size_t)N * 64u + 1u) / 2u + 1u) & ~(size_t)1u) * 8u +
-                       (3u * (size_t)B * 64u * sizeof(epv_meta_t) + 15u) / 16u * 16u;   // constants, matrix table, node table, meta cache
+  const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * 6u * 8u;     // constants, matrix table: once per block
+  const size_t per_wave_fixed = ((((size_t)N * 64u + 1u) / 2u + 1u) & ~(size_t)1u) * 8u +
+                                (3u * (size_t)B * 64u * sizeof(epv_meta_t) + 15u) / 16u * 16u;   // node table, meta cache
+  const size_t fixed = shared + per_wave_fixed;
   // one lane's worst case: every branch with 2C+1 segments (records K+1, heavy K)
   const uint64_t worst_rec = (uint64_t)B * (2u * C + 2u), worst_heavy = (uint64_t)B * (2u * C + 1u);
   const uint64_t worst_dbl = 2u * worst_rec + EPV_HREC * worst_heavy;
@@ -201,11 +204,13 @@ int plan_p2(epv_ctx *c) {
   const bool use_lds = std::getenv("EPV_FORCE_GLOBAL_POOL") ? false
                        : std::getenv("EPV_FORCE_LDS_POOL") ? want <= max_fit : lds_ok;
   if (fixed > 150u * 1024u) return fail(c, EPV_ERR_ARG, "tree too large for the 160 KiB LDS node table");
+  c->p2_waves = 1;
+  if (const char *e = std::getenv("EPV_P2_WAVES_PER_BLOCK")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->p2_waves = (uint32_t)v; }
   if (use_lds) {
     c->p2_gpool = false;
-    c->p2_pool = (uint32_t)want;
+    c->p2_pool = (uint32_t)((want + 1u) & ~(uint64_t)1u);
     c->p2_list_cap = 0;
-    c->p2_lds = fixed + (size_t)want * 8u;
+    c->p2_lds = shared + c->p2_waves * (per_wave_fixed + (size_t)c->p2_pool * 8u);
     return EPV_OK;
   }
   // global slab per wave: worst_rec rows of 64 interleaved records + a heavy list for the wave
@@ -223,7 +228,22 @@ int plan_p2(epv_ctx *c) {
   c->p2_gpool = true;
   c->p2_pool = (uint32_t)rows;
   c->p2_list_cap = (uint32_t)list_cap;
-  c->p2_lds = fixed;
+  c->p2_lds = shared + c->p2_waves * per_wave_fixed;
+  return EPV_OK;
+}
+
+// lists of the segment-parallel jump kernels, on first use
+int ensure_seg_buffers(epv_ctx *c) {
+  if (c->S.segs) return EPV_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t btask_cap = c->S.task_cap;
+  const uint64_t seg_cap = (uint64_t)((double)c->S.task_cap * std::min(8.0, std::max(0.5, 0.5 + 3.0 * c->kbar))) + 256u;
+  HIP_TRY(c, hipMalloc(&c->S.segs, seg_cap * EPV_SHARDS * sizeof(EpvSegTask)));
+  HIP_TRY(c, hipMalloc(&c->S.segout, seg_cap * EPV_SHARDS * sizeof(EpvSegOut)));
+  HIP_TRY(c, hipMalloc(&c->S.btasks, btask_cap * EPV_SHARDS * sizeof(unsigned long long)));
+  HIP_TRY(c, hipMalloc(&c->S.bfirst, btask_cap * EPV_SHARDS * sizeof(uint32_t)));
+  c->S.btask_cap = btask_cap;
+  c->S.seg_cap = seg_cap;
   return EPV_OK;
 }
 
@@ -328,15 +348,17 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   // fourteen branches does not repay the extra hand-over): profiles/r02_ab_seg_jumps.txt
   const bool seg_on = c->use_seg < 0 ? c->kbar >= 0.25 : c->use_seg != 0;
   const uint32_t seg_mode = (p2 && seg_on) ? 1u : 0u;
+  if (seg_mode) { const int src = ensure_seg_buffers(c); if (src) return src; }
   if (p2) {
     list_mode = 1u + (c->phase_parity & 1u);
+    const unsigned pt = 64u * c->p2_waves, pb = (unsigned)((threads + pt - 1u) / pt);
     if (c->p2_gpool)
-      hipLaunchKernelGGL(epv_mh_propose2_kernel<true>, dim3((unsigned)blocks), dim3(64), c->p2_lds, c->stream, c->S,
+      hipLaunchKernelGGL(epv_mh_propose2_kernel<true>, dim3(pb), dim3(pt), c->p2_lds, c->stream, c->S,
                          (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
                          c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, c->d_gpool2, c->d_segtab,
                          seg_mode);
     else
-      hipLaunchKernelGGL(epv_mh_propose2_kernel<false>, dim3((unsigned)blocks), dim3(64), c->p2_lds, c->stream, c->S,
+      hipLaunchKernelGGL(epv_mh_propose2_kernel<false>, dim3(pb), dim3(pt), c->p2_lds, c->stream, c->S,
                          (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
                          c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, (double *)nullptr, c->d_segtab,
                          seg_mode);
@@ -578,15 +600,8 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   // segment-parallel jump sampling: branch list as large as the task regions, segment list for
   // the expected number of dirty segments with a wide margin (what does not fit falls back to the
   // sequential kernel's lists)
-  {
-    const double kb = E ? (double)offsets[E] / (double)E : 0.0;
-    c->S.btask_cap = c->S.task_cap;
-    c->S.seg_cap = (uint64_t)((double)c->S.task_cap * std::min(8.0, std::max(0.5, 0.5 + 3.0 * kb))) + 256u;
-    HIP_TRY(c, hipMalloc(&c->S.segs, c->S.seg_cap * EPV_SHARDS * sizeof(EpvSegTask)));
-    HIP_TRY(c, hipMalloc(&c->S.segout, c->S.seg_cap * EPV_SHARDS * sizeof(EpvSegOut)));
-    HIP_TRY(c, hipMalloc(&c->S.btasks, c->S.btask_cap * EPV_SHARDS * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMalloc(&c->S.bfirst, c->S.btask_cap * EPV_SHARDS * sizeof(uint32_t)));
-  }
+  //   (allocated by ensure_seg_buffers when that path is first used)
+  c->S.btask_cap = c->S.seg_cap = 0;
   // accept list: one region per counter shard, room for every site of the blocks that use it
   c->S.alist_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u;
   HIP_TRY(c, hipMalloc(&c->S.alist, c->S.alist_cap * EPV_SHARDS * sizeof(uint32_t)));

@@ -77,8 +77,8 @@ __global__ void epv_segtab_kernel(EpvDev S, double *tab) {
 // from the front, K >= 4 from the back.  One atomic per wave and region reserves the slots.
 __device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long long *counters,
                                                 unsigned long long dirty, unsigned long long multi,
-                                                unsigned long long deep, uint32_t b, uint64_t site, int lane) {
-  const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+                                                unsigned long long deep, uint32_t b, uint64_t site, int lane,
+                                                uint32_t shard) {
 #pragma unroll
   for (uint32_t reg = 0; reg < 2u; ++reg) {
     const unsigned long long mine_reg = reg ? (dirty & deep) : (dirty & ~deep);
@@ -112,7 +112,7 @@ __device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long l
 #endif
 
 template <bool GPOOL>
-__global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel(
+__global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first,
     uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t pool_dbl, uint32_t list_cap,
     uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab, uint32_t seg_mode) {
@@ -125,23 +125,26 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
   const uint32_t tab_dbl = S.B * 4u * EPV_SEGTAB_DBL;
   const uint32_t regA_dbl = ((S.N * 64u + 1u) / 2u + 1u) & ~1u;
   const uint32_t mc_dbl = (3u * S.B * 64u * (uint32_t)sizeof(epv_meta_t) + 15u) / 16u * 2u;   // meta words of the three columns
+  // a block holds blockDim.x / 64 waves: constants and the matrix table once, then per wave the
+  // node table, the meta cache and the pool
+  const uint32_t wave_id = threadIdx.x >> 6;
+  // the counter shard and list regions are per WAVE (as if every wave were its own block)
+  const uint32_t my_shard = (blockIdx.x * (blockDim.x >> 6) + wave_id) & (EPV_SHARDS - 1u);
+  const uint32_t wave_dbl = regA_dbl + mc_dbl + (GPOOL ? 0u : ((pool_dbl + 1u) & ~1u));
   double *s_const = s_mem;
   double *s_tab = s_mem + const_dbl;
-  uint32_t *regA = reinterpret_cast<uint32_t *>(s_mem + const_dbl + tab_dbl);
+  double *s_wave = s_mem + const_dbl + tab_dbl + (size_t)wave_id * wave_dbl;
+  uint32_t *regA = reinterpret_cast<uint32_t *>(s_wave);
   // s_meta[(which * B + b) * 64 + lane], which = 0 left, 1 right, 2 this site: fetched ONCE, in one
   // batch of independent loads; the four passes below then read LDS instead of paying a global
   // round trip per branch (the kernel is bound by memory latency, not by issue)
-  epv_meta_t *s_meta = reinterpret_cast<epv_meta_t *>(s_mem + const_dbl + tab_dbl + regA_dbl);
+  epv_meta_t *s_meta = reinterpret_cast<epv_meta_t *>(s_wave + regA_dbl);
   const int lane = epv_lane();
   // GPOOL: rows of 64 interleaved records (row r of lane l at (r * 64 + l) * 2 doubles), then
   // the flat heavy list; LDS: records packed by a wave prefix sum, the heavy list behind them
-  double *pool = GPOOL ? gpool + (size_t)blockIdx.x * ((size_t)pool_dbl * 128u + (size_t)list_cap * EPV_HREC)
-                       : s_mem + const_dbl + tab_dbl + regA_dbl + mc_dbl;
-  for (uint32_t i = threadIdx.x; i < tab_dbl; i += blockDim.x) s_tab[i] = segtab[i];
-  stage_constants(S, s_const);
-  const double *s_rates = s_const;
-  const double *s_blen = s_const + 20;
-
+  double *pool = GPOOL ? gpool + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_id) *
+                                     ((size_t)pool_dbl * 128u + (size_t)list_cap * EPV_HREC)
+                       : s_wave + regA_dbl + mc_dbl;
   const uint64_t gfirst = S.g0 + first;
   const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,10 +155,17 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
   const uint32_t gsite = (uint32_t)(S.g0 + site);
   const uint32_t gsite_lane0 = gsite - 3u * (uint32_t)lane;
 
+  // the head of the kernel's dependent chain (sel -> meta -> jumps) starts before the constants are
+  // staged, so that the two round trips overlap
   uint32_t selL = 0, selM = 0, selR = 0;
+  if (valid) { selL = S.sel[site - 1]; selM = S.sel[site]; selR = S.sel[site + 1]; }
+  for (uint32_t i = threadIdx.x; i < tab_dbl; i += blockDim.x) s_tab[i] = segtab[i];
+  stage_constants(S, s_const);
+  const double *s_rates = s_const;
+  const double *s_blen = s_const + 20;
+
   uint32_t need_rec = 0, heavy = 0;
   if (valid) {
-    selL = S.sel[site - 1]; selM = S.sel[site]; selR = S.sel[site + 1];
 #pragma unroll 4
     for (uint32_t b = 0; b < B; ++b) {
       const uint32_t mL = S.meta[meta_idx(S, selL, b, site - 1)];
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
         const uint32_t inclS = wave_incl_scan_u32(wS), inclB = wave_incl_scan_u32(wB);
         const uint32_t totS = __shfl(inclS, 63), totB = __shfl(inclB, 63);
         if (totB) {
-          const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+          const uint32_t shard = my_shard;
           unsigned long long base = 0ull;
           if (lane == 0)
             base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_SEG, shard)],
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
         if (Kb >= 3u) deep |= 1ull << (b & 63u);
       }
       if ((b & 63u) == 63u || node + 1u == S.N) {
-        epv_flush_tasks(S, counters, dirty, multi, deep, b, site, lane);
+        epv_flush_tasks(S, counters, dirty, multi, deep, b, site, lane, my_shard);
         dirty = multi = deep = 0ull;
       }
     }
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel
       S.prop_flag[tid] = 0u;
     }
     {
-      const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
+      const uint32_t shard = my_shard;
       const unsigned long long lm = __ballot(to_list);
       if (lm) {
         unsigned long long base = 0ull;
