@@ -27,7 +27,7 @@ BIN_DIR = os.path.join(PKG, "bin")
 
 HOST_SOURCES = ["epv_model.cpp", "epv_sim.cpp", "epv_io.cpp", "epv_indep.cpp", "epv_forward.cpp", "epv_host_abi.cpp"]
 # the reference library is built -O3 without -march (no FMA contraction); match it
-HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall"]
+HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-pthread"]
 
 
 def _newer(target, sources):

@@ -28,7 +28,7 @@ int main(int argc, const char **argv) {
     string pathfile, tree_file, root_states_file;
     bool VERBOSE = false, unscaled_model_params = false, scale_time = false, TRPARAM = false,
          write_only_leaves = false;
-    size_t n_sites = 100;
+    size_t n_sites = 100, n_threads = 1;
     double evolutionary_time = std::numeric_limits<double>::lowest();
     size_t rng_seed = std::numeric_limits<size_t>::max();
 
@@ -45,6 +45,10 @@ int main(int argc, const char **argv) {
     opt_parse.add_opt("scale-time", '\0', "scale time", false, scale_time);
     opt_parse.add_opt("rates", 'R', "use triplet transition rates", false, TRPARAM);
     opt_parse.add_opt("verbose", 'v', "print more run info", false, VERBOSE);
+    // extension: sibling subtrees on their own threads, one generator per branch seeded from
+    // (seed, node).  1 (default) = the reference's single sequential stream
+    opt_parse.add_opt("threads", 'j', "simulate sibling subtrees in parallel on this many threads "
+                      "(other random stream than the default)", false, n_threads);
     vector<string> leftover_args;
     opt_parse.parse(argc, argv, leftover_args);
     if (argc == 1 || opt_parse.help_requested()) {
@@ -99,7 +103,12 @@ int main(int argc, const char **argv) {
     vector<vector<uint8_t>> sequences;
     vector<vector<epv::GlobalJump>> paths;
     vector<size_t> events;
-    epv::simulate_tree(the_model, th, root_seq, gen, sequences, paths, events);
+    if (n_threads > 1) {
+      if (VERBOSE) cerr << "[PARALLEL MODE: one generator per branch, up to " << n_threads << " threads]" << endl;
+      epv::simulate_tree_parallel(the_model, th, root_seq, rng_seed, (int)n_threads, sequences, paths, events);
+    } else {
+      epv::simulate_tree(the_model, th, root_seq, gen, sequences, paths, events);
+    }
     epv::write_global_jumps(pathfile, th.node_names, root_seq, paths);
     if (VERBOSE) {
       cerr << "[FREQUENCIES OF SAMPLED EVENTS]" << endl;

@@ -1,6 +1,9 @@
 // epv_forward.cpp -- see epv_forward.hpp
 #include "epv_forward.hpp"
 
+#include <atomic>
+#include <thread>
+
 #include <algorithm>
 #include <cstdio>
 #include <fstream>
@@ -138,6 +141,65 @@ void simulate_tree(const Model &m, const Tree &th, const std::vector<uint8_t> &r
     simulate_branch(m, th.branches[node], gen, index, paths[node], events);
     index.sequence(sequences[node]);
   }
+}
+
+// Sibling subtrees in parallel (new; the reference threads ONE std::mt19937 through the branches
+// in pre-order, epievo_sim.cpp:329-352, so its stream cannot be split).  Once a node's end
+// sequence is known its children are independent: every branch gets its own generator seeded
+// from (seed, node index), a node's children run on their own threads while the budget lasts,
+// and the result depends on the seed and the tree only -- not on the number of threads.  The law
+// of the process is the reference's (same sample_jump per event); the numbers differ from the
+// sequential mode's, which stays the default and the one pinned to the linked TripletSampler.
+namespace {
+struct ParSim {
+  const Model &m;
+  const Tree &th;
+  uint64_t seed;
+  std::vector<std::vector<uint8_t>> &sequences;
+  std::vector<std::vector<GlobalJump>> &paths;
+  std::vector<std::vector<size_t>> events;   // per node
+  std::atomic<int> budget;
+  ParSim(const Model &m_, const Tree &th_, uint64_t seed_, std::vector<std::vector<uint8_t>> &sq,
+         std::vector<std::vector<GlobalJump>> &pp, int threads)
+      : m(m_), th(th_), seed(seed_), sequences(sq), paths(pp), events(th_.n_nodes(), std::vector<size_t>(8, 0)),
+        budget(threads - 1) {}
+  void subtree(int node) {
+    if (node > 0) {
+      std::seed_seq sq{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)node, 0x65707673u};
+      std::mt19937 gen(sq);
+      ContextIndex index(sequences[th.parent_ids[node]]);
+      simulate_branch(m, th.branches[node], gen, index, paths[node], events[node]);
+      index.sequence(sequences[node]);
+    }
+    std::vector<std::thread> spawned;
+    std::vector<int> kids;
+    for (uint32_t c = 1; c < th.subtree_sizes[node]; c += th.subtree_sizes[node + c]) kids.push_back(node + (int)c);
+    for (size_t i = 0; i < kids.size(); ++i) {
+      const int k = kids[i];
+      if (i + 1 < kids.size() && budget.fetch_sub(1) > 0) {
+        spawned.emplace_back([this, k] { subtree(k); budget.fetch_add(1); });
+      } else {
+        if (i + 1 < kids.size()) budget.fetch_add(1);   // the failed reservation
+        subtree(k);
+      }
+    }
+    for (std::thread &t : spawned) t.join();
+  }
+};
+}  // namespace
+
+void simulate_tree_parallel(const Model &m, const Tree &th, const std::vector<uint8_t> &root_seq, uint64_t seed,
+                            int threads, std::vector<std::vector<uint8_t>> &sequences,
+                            std::vector<std::vector<GlobalJump>> &paths, std::vector<size_t> &events) {
+  const int N = th.n_nodes();
+  sequences.assign(N, {});
+  sequences[0] = root_seq;
+  paths.assign(N, {});
+  ParSim ps(m, th, seed, sequences, paths, std::max(1, threads));
+  ps.subtree(0);
+  events.assign(8, 0);
+  for (int node = 1; node < N; ++node)
+    for (size_t c = 0; c < 8; ++c) events[c] += ps.events[node][c];
 }
 
 void write_global_jumps(const std::string &file, const std::vector<std::string> &node_names,

@@ -56,6 +56,12 @@ void simulate_tree(const Model &m, const Tree &th, const std::vector<uint8_t> &r
                    std::mt19937 &gen, std::vector<std::vector<uint8_t>> &sequences,
                    std::vector<std::vector<GlobalJump>> &paths, std::vector<size_t> &events);
 
+// the same process with sibling subtrees on their own threads and one generator per branch,
+// seeded from (seed, node): independent of the number of threads, NOT the sequential stream
+void simulate_tree_parallel(const Model &m, const Tree &th, const std::vector<uint8_t> &root_seq, uint64_t seed,
+                            int threads, std::vector<std::vector<uint8_t>> &sequences,
+                            std::vector<std::vector<GlobalJump>> &paths, std::vector<size_t> &events);
+
 // global_jumps file (GlobalJump.cpp:71-140) and the states file writer (epievo_sim.cpp:66-96)
 void write_global_jumps(const std::string &file, const std::vector<std::string> &node_names,
                         const std::vector<uint8_t> &root, const std::vector<std::vector<GlobalJump>> &paths);

@@ -90,3 +90,42 @@ def test_sim_and_convert_clis(tmp_path):
     r = subprocess.run([os.path.join(_build.BIN_DIR, "epievo_sim"), d + "/p.param", d + "/y.states"],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "specify exactly one of: tree or time" in r.stderr
+
+
+def test_parallel_forward_sim_mode(tmp_path):
+    """epievo_sim -j N (new): sibling subtrees on their own threads, one std::mt19937 per branch
+    seeded from (seed, node).  The output depends on the seed and the tree only -- not on N -- and
+    is another realisation of the same process as the sequential mode (which stays pinned to the
+    linked TripletSampler above); a fixed-seed digest pins the mode against regressions."""
+    import hashlib
+    d = str(tmp_path)
+    open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+    n = 20000
+    ev = {}
+    for j in (1, 2, 8):
+        r = subprocess.run([os.path.join(_build.BIN_DIR, "epievo_sim"), "-v", "-n", str(n), "-s", "42", "-j", str(j),
+                            "-p", d + "/g%d.jumps" % j, "-t", d + "/t.nwk", d + "/p.param", d + "/x%d.states" % j],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        ev[j] = int([l for l in r.stderr.split("\n") if "TOTAL SAMPLED EVENTS" in l][0].split(":")[1].strip(" ]"))
+    g = {j: open(d + "/g%d.jumps" % j, "rb").read() for j in (1, 2, 8)}
+    x = {j: open(d + "/x%d.states" % j, "rb").read() for j in (1, 2, 8)}
+    assert g[2] == g[8] and x[2] == x[8]                 # independent of the number of threads
+    assert g[1] != g[2]                                   # not the sequential stream
+    assert abs(ev[2] - ev[1]) < 6 * np.sqrt(ev[1])        # the same process: event counts agree (Poisson)
+    assert hashlib.sha256(g[2]).hexdigest()[:16] == PARALLEL_DIGEST, hashlib.sha256(g[2]).hexdigest()[:16]
+    # the parallel output is a valid history: global_jumps_to_paths reproduces the states file
+    r = subprocess.run([os.path.join(_build.BIN_DIR, "global_jumps_to_paths"), "-t", d + "/t.nwk", d + "/x2.states",
+                        d + "/g2.jumps", d + "/x2.paths"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fp, names, tt = host.read_paths(d + "/x2.paths")
+    tree = config("tree")
+    B = tree.n_nodes - 1
+    end = fp.init.reshape(B, n) ^ (fp.counts().reshape(B, n) & 1).astype(np.uint8)
+    st = np.loadtxt(d + "/x2.states", dtype=np.int64, skiprows=1)[:, 1:].T.astype(np.uint8)   # [node][site]
+    for b in range(1, tree.n_nodes):
+        assert np.array_equal(end[b - 1], st[b]) and np.array_equal(fp.init.reshape(B, n)[b - 1], st[tree.parent_ids[b]])
+
+
+PARALLEL_DIGEST = "e0cae3586c452ba4"
