@@ -12,10 +12,10 @@ from epievo_amd import _build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "epievo_mi355x.h")).read()
+def _declared(header="epievo_mi355x.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(epv_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(epv_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -27,6 +27,22 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     from epievo_amd.sampler import ABI_SYMBOLS
     assert sorted(ABI_SYMBOLS) == names
+
+
+def test_exchange_library_exports_every_declared_symbol():
+    """include/epievo_mi355x_comm.h -> libepv_rccl.so (links librccl; loads without a GPU)"""
+    assert os.path.exists(_build.COMM_SO), "run __graft_entry__.build() first"
+    L = ctypes.CDLL(_build.COMM_SO)
+    names = _declared("epievo_mi355x_comm.h")
+    assert len(names) >= 12
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # no device here: setting up ranks fails cleanly (no fallback transport for a missing GPU)
+    import torch
+    if not torch.cuda.is_available():
+        comms = (ctypes.c_void_p * 2)()
+        devs = (ctypes.c_int * 2)(0, 0)
+        assert L.epv_comm_init_all(2, devs, comms) != 0
 
 
 def test_no_cpu_fallback():
