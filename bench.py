@@ -169,7 +169,8 @@ def main():
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
-            comm = TorchComm(dist)
+            # the buffers stay on the GPU; gloo cannot move them, TorchComm bounces them through the host
+            comm = TorchComm(dist, torch.device("cuda", local_rank))
     else:
         comm = NullComm()
 
@@ -298,7 +299,7 @@ def main():
                                    "%d GPU shard(s) x %d concurrent context(s) per GPU" % (ss.halo, world, k_eff)},
             # frac = what the DEVICE sustains: k_eff launches (one per context of this GPU) run
             # concurrently, each timed with its own HIP events on its own stream
-            "roofline": {"bound": "hbm", "kernel": "epv_mh_propose_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel (one colour phase = one timed launch triple)",
+            "roofline": {"bound": "hbm", "kernel": "epv_mh_propose2_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel (one colour phase = one timed launch triple; large trees: epv_mh_propose_kernel)",
                          "achieved": achieved_device,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_device / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_resample": bytes_per,
