@@ -23,3 +23,25 @@ def test_rccl_one_rank_selfcheck():
                         os.path.join(ROOT, "tools", "nccl_selfcheck.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "nccl selfcheck ok: world 1" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per process),
+    with the gloo backend so that both ranks can use the one GPU of the test box: the whole N > 1
+    path -- row-aligned shards, the halo exchange of 512 columns, the all-gather of the statistic
+    rows -- runs on the HIP kernels and rank 0 prints the one JSON line"""
+    import json
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--backend", "gloo", "--sites", "200000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 1e8
+    assert "512-column redundant halos" in j["config"]["sharding"] and "cpu_baseline" not in j
