@@ -13,6 +13,7 @@
 #include <limits>
 #include <random>
 #include <stdexcept>
+#include <thread>
 
 #include "epv_io.hpp"
 #include "epv_model.hpp"
@@ -117,6 +118,15 @@ int main(int argc, const char **argv) {
            << "\t" << the_model.baseline[3] << endl;
     }
 
+    // The reference rewrites the paths file after every iteration (:280-283).  Formatting and
+    // writing 111 MB (n = 1e6, tree.nwk) takes longer than the E-step of the next iteration, and
+    // that E-step needs only the device-resident paths: the file of iteration i is written by a
+    // background thread while the GPU runs iteration i + 1 (same bytes, same order of files).
+    std::thread writer;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{writer};   // also on the error path
+    std::string writer_error;
+    epv::FlatPaths out_paths;
+    vector<double> out_branches;
     epv::SingleSiteSampler mcmc(burnin, batch,
                                 gpu_list.empty() ? epv::devices_from_env() : epv::parse_device_list(gpu_list));
     for (size_t itr = 0; itr < iteration; itr++) {
@@ -156,15 +166,24 @@ int main(int argc, const char **argv) {
         if (!out_param) throw std::runtime_error("bad output param file: " + param_file_updated);
         out_param << the_model.format_for_param_file() << endl;
       }
-      mcmc.download(paths);
-      epv::write_local_paths(outfile, th.node_names, th.n_nodes(), paths.n_sites, th.branches.data(),
-                             paths.init.data(), paths.offsets.data(), paths.jumps.data());
+      if (writer.joinable()) writer.join();
+      if (!writer_error.empty()) throw std::runtime_error(writer_error);
+      mcmc.download(out_paths);
+      out_branches = th.branches;
+      writer = std::thread([&outfile, &th, &out_paths, &out_branches, &writer_error] {
+        try {
+          epv::write_local_paths(outfile, th.node_names, th.n_nodes(), out_paths.n_sites, out_branches.data(),
+                                 out_paths.init.data(), out_paths.offsets.data(), out_paths.jumps.data());
+        } catch (const std::exception &e) { writer_error = e.what(); }
+      });
       if (optimize_branches && !treefile_updated.empty()) {
         std::ofstream out_tree(treefile_updated);
         if (!out_tree) throw std::runtime_error("bad output param file: " + treefile_updated);
         out_tree << th.newick() << endl;
       }
     }
+    if (writer.joinable()) writer.join();
+    if (!writer_error.empty()) throw std::runtime_error(writer_error);
   } catch (const std::exception &e) {
     cerr << e.what() << endl;
     return EXIT_FAILURE;
