@@ -154,6 +154,7 @@ FlatPaths read_local_paths(const std::string &path_file, std::vector<std::string
     std::vector<double> jumps;
     double tot_time = 0.0;
     bool have_tt = false;
+    std::string tt_text;   // the first row's tot_time token
   };
   std::vector<NodeRows> rows;
   std::string line;
@@ -167,25 +168,40 @@ FlatPaths read_local_paths(const std::string &path_file, std::vector<std::string
     // "site\tinit\ttot_time\tjump\tjump..." ; tokens are whitespace separated
     const char *p = line.c_str();
     char *end = nullptr;
-    std::strtoull(p, &end, 10);  // site index (ignored, rows are in order)
-    if (end == p) continue;      // blank line
-    p = end;
-    const long is = std::strtol(p, &end, 10);
-    p = end;
-    const double tt = std::strtod(p, &end);
-    p = end;
     NodeRows &nr = rows.back();
-    if (!nr.have_tt) { nr.tot_time = tt; nr.have_tt = true; }
-    else if (tt != nr.tot_time)
-      throw std::runtime_error("paths of one node disagree on tot_time: " + path_file);
-    nr.init.push_back(is != 0);
+    // fast path for the common row "<site>\t<0|1>\t<tot_time>\t[jumps...]": digits, one state
+    // character, and a tot_time token that repeats the node's first one byte for byte (then its
+    // value is known without another strtod)
+    const char *q = p;
+    while (*q >= '0' && *q <= '9') ++q;
+    if (q != p && *q == '\t' && (q[1] == '0' || q[1] == '1') && q[2] == '\t' && nr.have_tt &&
+        line.compare((size_t)(q + 3 - p), nr.tt_text.size(), nr.tt_text) == 0 &&
+        (q[3 + nr.tt_text.size()] == '\t' || q[3 + nr.tt_text.size()] == '\0')) {
+      nr.init.push_back(q[1] == '1');
+      p = q + 3 + nr.tt_text.size();
+    } else {
+      std::strtoull(p, &end, 10);  // site index (ignored, rows are in order)
+      if (end == p) continue;      // blank line
+      p = end;
+      const long is = std::strtol(p, &end, 10);
+      p = end;
+      while (*p == ' ' || *p == '\t') ++p;
+      const double tt = std::strtod(p, &end);
+      if (!nr.have_tt) { nr.tot_time = tt; nr.have_tt = true; nr.tt_text.assign(p, (size_t)(end - p)); }
+      else if (tt != nr.tot_time)
+        throw std::runtime_error("paths of one node disagree on tot_time: " + path_file);
+      p = end;
+      nr.init.push_back(is != 0);
+    }
     uint64_t c = 0;
-    for (;;) {
+    while (*p == '\t' || *p == ' ') ++p;
+    while (*p) {             // most rows end here: no jumps
       const double v = std::strtod(p, &end);
       if (end == p) break;
       nr.jumps.push_back(v);
       ++c;
       p = end;
+      while (*p == '\t' || *p == ' ') ++p;
     }
     nr.cnt.push_back(c);
   }
