@@ -734,11 +734,24 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
   // Only the first `tasks_per_wave` lanes of a wave own a task; the others are pure
   // helpers for the cooperative search.  Fewer tasks per wave = more waves in flight and a
   // shorter critical path for the rare very hard task (1/P(a->b) in the hundreds).
-  const unsigned long long stride = (unsigned long long)gridDim.x * 4u * tasks_per_wave;
-  for (unsigned long long base = ((unsigned long long)blockIdx.x * 4u + wave) * tasks_per_wave;
-       base < n_tasks; base += stride) {
+  // Work is handed out in chunks, one per wave and pass.  The DEEP tasks (K >= 3 segments: the
+  // long loops) come first and in small chunks -- a quarter of tasks_per_wave -- so that the
+  // longest chains start early and stall fewer neighbours; the shallow ones (K <= 2) follow.
+#ifdef EPV_JUMPS_UNIFORM_CHUNKS
+  const uint32_t tpw_deep = tasks_per_wave;
+#else
+  const uint32_t tpw_deep = tasks_per_wave >= 32u ? tasks_per_wave / 4u : tasks_per_wave;
+#endif
+  const unsigned long long n_deep = n_tasks - n1;
+  const unsigned long long W2 = (n_deep + tpw_deep - 1u) / tpw_deep, W1 = (n1 + tasks_per_wave - 1u) / tasks_per_wave;
+  for (unsigned long long cidx = (unsigned long long)blockIdx.x * 4u + wave; cidx < W1 + W2;
+       cidx += (unsigned long long)gridDim.x * 4u) {
+    const bool deep_chunk = cidx < W2;
+    const uint32_t my_tpw = deep_chunk ? tpw_deep : tasks_per_wave;
+    const unsigned long long base = deep_chunk ? n1 + cidx * tpw_deep : (cidx - W2) * tasks_per_wave;
+    const unsigned long long limit = deep_chunk ? n_tasks : n1;
     const unsigned long long ti = base + (unsigned)lane;
-    bool active = (uint32_t)lane < tasks_per_wave && ti < n_tasks;
+    bool active = (uint32_t)lane < my_tpw && ti < limit;
     uint64_t site = 0, ptid = 0;
     uint32_t b = 0, node = 1, gsite = 0, start_state = 0, prev = 0, cnt = 0, k = 0;
     uint32_t trip0 = 0, i = 0, j = 0;
