@@ -178,9 +178,10 @@ int plan_mh(epv_ctx *c) {
 // table and a pool of doubles shared by the Felsenstein records (2 doubles) and the heavy-segment
 // records (EPV_HREC doubles).  The pool covers the typical demand of 64 lanes with a margin (a wave that
 // needs more runs in rounds) and always one lane's worst case.
+bool seg_jumps_on(const epv_ctx *c) { return c->use_seg < 0 ? c->kbar >= 0.25 : c->use_seg != 0; }
 double p2_margin() {
   if (const char *e = std::getenv("EPV_P2_MARGIN")) { const double v = std::atof(e); if (v >= 1.0 && v <= 4.0) return v; }
-  return 1.25;
+  return 1.15;     // 1.25 -> 1.15 with the 8-double records: one more wave per CU, ~4 % of the waves take a second round
 }
 int plan_p2(epv_ctx *c) {
   const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
@@ -190,14 +191,16 @@ int plan_p2(epv_ctx *c) {
   const size_t fixed = shared + per_wave_fixed;
   // one lane's worst case: every branch with 2C+1 segments (records K+1, heavy K)
   const uint64_t worst_rec = (uint64_t)B * (2u * C + 2u), worst_heavy = (uint64_t)B * (2u * C + 1u);
-  const uint64_t worst_dbl = 2u * worst_rec + EPV_HREC * worst_heavy;
+  // heavy-segment records: 8 doubles, 10 when the segment-parallel jump kernels read them back
+  const uint64_t hrec = seg_jumps_on(c) ? EPV_HREC : EPV_HREC_SHORT;
+  const uint64_t worst_dbl = 2u * worst_rec + hrec * worst_heavy;
   // typical: K = 1 + Poisson(2 kbar) segments per branch; heavy segments E[K; K >= 2]
   const double lam = 2.0 * c->kbar;
   const double heavy_per_branch = (1.0 + lam) - std::exp(-lam);
   uint32_t n_internal = 0;
   for (uint32_t node = 1; node < N; ++node) n_internal += c->subtree[node] != 1u;
   const double rec_per_lane = B * (1.0 + lam) + n_internal;     // K per branch, +1 for an internal node's q
-  const uint64_t typical_dbl = (uint64_t)(64.0 * (2.0 * rec_per_lane + (double)EPV_HREC * B * heavy_per_branch) * p2_margin()) + 64u;
+  const uint64_t typical_dbl = (uint64_t)(64.0 * (2.0 * rec_per_lane + (double)hrec * B * heavy_per_branch) * p2_margin()) + 64u;
   const uint64_t max_fit = fixed + 64u < 160u * 1024u ? (160u * 1024u - fixed) / 8u : 0u;
   const uint64_t want = std::max(worst_dbl, typical_dbl);
   const bool lds_ok = want <= max_fit && (fixed + want * 8u) * 5u <= 160u * 1024u;   // >= 5 waves per CU
@@ -346,22 +349,16 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   // segment-parallel jumps pay on long branches (single branch T = 1: +17 %, every segment is
   // dirty and needs several trials) and cost on short ones (tree.nwk: -12 %, one dirty segment in
   // fourteen branches does not repay the extra hand-over): profiles/r02_ab_seg_jumps.txt
-  const bool seg_on = c->use_seg < 0 ? c->kbar >= 0.25 : c->use_seg != 0;
-  const uint32_t seg_mode = (p2 && seg_on) ? 1u : 0u;
+  const uint32_t seg_mode = (p2 && seg_jumps_on(c)) ? 1u : 0u;
   if (seg_mode) { const int src = ensure_seg_buffers(c); if (src) return src; }
   if (p2) {
     list_mode = 1u + (c->phase_parity & 1u);
     const unsigned pt = 64u * c->p2_waves, pb = (unsigned)((threads + pt - 1u) / pt);
-    if (c->p2_gpool)
-      hipLaunchKernelGGL(epv_mh_propose2_kernel<true>, dim3(pb), dim3(pt), c->p2_lds, c->stream, c->S,
-                         (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
-                         c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, c->d_gpool2, c->d_segtab,
-                         seg_mode);
-    else
-      hipLaunchKernelGGL(epv_mh_propose2_kernel<false>, dim3(pb), dim3(pt), c->p2_lds, c->stream, c->S,
-                         (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
-                         c->p2_pool, c->p2_list_cap, c->phase_parity & 1u, c->d_counters, (double *)nullptr, c->d_segtab,
-                         seg_mode);
+    auto kern = c->p2_gpool ? (seg_mode ? epv_mh_propose2_kernel<true, true> : epv_mh_propose2_kernel<true, false>)
+                            : (seg_mode ? epv_mh_propose2_kernel<false, true> : epv_mh_propose2_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3(pb), dim3(pt), c->p2_lds, c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->p2_pool, c->p2_list_cap,
+                       c->phase_parity & 1u, c->d_counters, c->p2_gpool ? c->d_gpool2 : (double *)nullptr, c->d_segtab);
     ++c->phase_parity;
   } else {
     auto kern = c->mh_gpool ? (refq ? epv_mh_propose_kernel<true, true> : epv_mh_propose_kernel<true, false>)
@@ -479,9 +476,13 @@ EPV_API epv_ctx *epv_create(int device_id) {
     return nullptr;
   }
   // the MH kernel asks for more dynamic LDS than the 64 KiB default
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<true>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1442,6 +1443,18 @@ EPV_API int epv_get_counters(epv_ctx *c, epv_counters *out) {
   out->reserved = 0;
   return EPV_OK;
 }
+
+#ifdef EPV_P2_PROFILE
+// sums over the per-wave rows: out[0..6] section cycles, out[7] waves
+EPV_API int epv_debug_p2_profile(unsigned long long *out) {
+  std::vector<unsigned long long> rows(8u * EPV_P2_PROF_ROWS);
+  if (hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(epv_p2_prof), rows.size() * sizeof(unsigned long long)) != hipSuccess) return 1;
+  for (int q = 0; q < 8; ++q) out[q] = 0;
+  for (size_t r = 0; r < EPV_P2_PROF_ROWS; ++r)
+    for (int q = 0; q < 8; ++q) out[q] += rows[8u * r + q];
+  return 0;
+}
+#endif
 
 EPV_API int epv_set_timing(epv_ctx *c, int enabled) {
   if (!c) return EPV_ERR_ARG;

@@ -41,6 +41,8 @@ struct EpvSegRec {      // one segment, everything the recursions need
 };
 #define EPV_SEGTAB_DBL 6u   /* table entry = the first six fields */
 #define EPV_HREC 10u        /* doubles per heavy-segment record: the eight fields, length, address word */
+#define EPV_HREC_SHORT 8u   /* ... when nothing reads length and address word after the dense evaluation
+                               (sequential jump kernel): they are parked in the slots of the two uniforms */
 
 __device__ __forceinline__ void epv_seg_matrices(double len, double r0, double r1, double out[6]) {
   const double denom = r0 + r1;
@@ -111,16 +113,31 @@ __device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long l
 #define EPV_PROPOSE2_WAVES 3
 #endif
 
-template <bool GPOOL>
+// -DEPV_P2_PROFILE: wave-time per section of the kernel, read back by tools/p2_profile.py
+#ifdef EPV_P2_PROFILE
+// one row per wave and plain stores: atomics on shared counters would serialise the waves and
+// show up as waiting time wherever the compiler put the next s_waitcnt
+#define EPV_P2_PROF_ROWS 8192
+__device__ unsigned long long epv_p2_prof[8 * EPV_P2_PROF_ROWS];
+#define P2_MARK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc_[i] += t_ - t_prev_; t_prev_ = t_; } while (0)
+#else
+#define P2_MARK(i) do {} while (0)
+#endif
+template <bool GPOOL, bool SEG>
 __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first,
     uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t pool_dbl, uint32_t list_cap,
-    uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab, uint32_t seg_mode) {
-  // seg_mode: 1 = dirty SEGMENTS go to the segment-parallel jump kernels (epv_jumps2.h); 0 = dirty
+    uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab) {
+  // SEG: true = dirty SEGMENTS go to the segment-parallel jump kernels (epv_jumps2.h); 0 = dirty
   // branches go to epv_mh_jumps_kernel's bucketed lists
   // pool_dbl: LDS pool -- doubles per wave; GPOOL -- record ROWS per lane (list_cap heavy records
   // behind them; unused for the LDS pool, where records and list share pool_dbl)
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  constexpr uint32_t HREC = SEG ? EPV_HREC : EPV_HREC_SHORT, LEN_AT = HREC - 2u, INFO_AT = HREC - 1u;
+#ifdef EPV_P2_PROFILE
+  unsigned long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
   const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
   const uint32_t tab_dbl = S.B * 4u * EPV_SEGTAB_DBL;
   const uint32_t regA_dbl = ((S.N * 64u + 1u) / 2u + 1u) & ~1u;
@@ -180,13 +197,14 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
     }
   }
 
+  P2_MARK(0);
   bool pending = valid;
   while (__any(pending)) {
     const uint32_t wantR = pending ? need_rec : 0u, wantH = pending ? heavy : 0u;
     const uint32_t inclR = wave_incl_scan_u32(wantR), inclH = wave_incl_scan_u32(wantH);
     // non-decreasing in the lane index, so the lanes that run are a prefix of the pending ones
     const bool run = pending && (GPOOL ? (need_rec <= pool_dbl && inclH <= list_cap)
-                                       : (2u * inclR + EPV_HREC * inclH <= pool_dbl));
+                                       : (2u * inclR + HREC * inclH <= pool_dbl));
     const unsigned long long rmask = __ballot(run);
     const int hi_lane = rmask ? 63 - __clzll((long long)rmask) : 0;
     const uint32_t totR = rmask ? __shfl(inclR, hi_lane) : 0u, totH = rmask ? __shfl(inclH, hi_lane) : 0u;
@@ -195,6 +213,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
     double *list = GPOOL ? pool + (size_t)pool_dbl * 128u : pool + (size_t)totR * 2u;
     const uint32_t hbase = inclH - wantH;
 
+    P2_MARK(1);
     // ---- 1. list the heavy segments: forward merge of the neighbours' jumps (Segment.cpp:35-79)
     if (run && heavy) {
       uint32_t hcur = hbase;
@@ -213,9 +232,9 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
           const bool last_seg = (k + 1u == K);
           const bool take_left = tl < tr;
           const double seg_end = last_seg ? s_blen[node] : (take_left ? tl : tr);
-          double *rec = list + (size_t)(hcur + k) * EPV_HREC;
-          rec[8] = seg_end - seg_start;
-          rec[9] = epv_u2d((uint64_t)trip0 | ((uint64_t)lane << 3) | ((uint64_t)node << 9) | ((uint64_t)k << 21));
+          double *rec = list + (size_t)(hcur + k) * HREC;
+          rec[LEN_AT] = seg_end - seg_start;
+          rec[INFO_AT] = epv_u2d((uint64_t)trip0 | ((uint64_t)lane << 3) | ((uint64_t)node << 9) | ((uint64_t)k << 21));
           if (!last_seg) {
             if (take_left) { trip0 ^= 4u; ++i; tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF; }
             else { trip0 ^= 1u; ++j; tr = j < R.nj ? R.j[(uint64_t)j * n] : EPV_INF; }
@@ -228,11 +247,12 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    P2_MARK(2);
     // ---- 2. evaluate them densely, one segment per lane
     for (uint32_t i = (uint32_t)lane; i < totH; i += 64u) {
-      double *rec = list + (size_t)i * EPV_HREC;
-      const double len = rec[8];
-      const uint64_t info = epv_d2u(rec[9]);
+      double *rec = list + (size_t)i * HREC;
+      const double len = rec[LEN_AT];
+      const uint64_t info = epv_d2u(rec[INFO_AT]);
       const uint32_t trip0 = (uint32_t)info & 7u, owner = (uint32_t)(info >> 3) & 63u;
       const uint32_t node = (uint32_t)(info >> 9) & 4095u, k = (uint32_t)(info >> 21);
       double m[6];
@@ -246,6 +266,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    P2_MARK(3);
     bool ident = true;
     if (run) {
       // ---- 3. pruning, reverse pre-order (SingleSiteSampler.cpp:116-157)
@@ -282,7 +303,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         } else {
           hcur -= K;
           for (uint32_t kk = K; kk-- > 0u;) {
-            const double *hr = list + (size_t)(hcur + kk) * EPV_HREC;
+            const double *hr = list + (size_t)(hcur + kk) * HREC;
             const double P00 = hr[0], P11 = hr[1];
             const double P01 = 1.0 - P00, P10 = 1.0 - P11;
             const double a = P00 * n0 + P01 * n1;
@@ -295,6 +316,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       }
     }
 
+    P2_MARK(4);
     // ---- 4. downward sampling of the segment END STATES (:180-255); the jump times are drawn
     //         by epv_mh_jumps_kernel for the dirty branches only (see epv_kernels.h).  The node
     //         loop is wave-uniform: the task flush inside it is a wave-wide operation.
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
             const epv_block2 blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, 0u, 0u, 0u);
             u_end = blk.d0; u_first = blk.d1;
           } else {
-            const double *hr = list + (size_t)(hcur + k) * EPV_HREC;
+            const double *hr = list + (size_t)(hcur + k) * HREC;
             PT0 = prev ? hr[3] : hr[2];
             nb = prev ? hr[5] : hr[4];
             u_end = hr[6]; u_first = hr[7];
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         trip_b = 4u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT);
       }
       bool old_list = dirty_b;
-      if (seg_mode) {
+      if (SEG) {
         // ---- dirty SEGMENTS onto the segment list (one lane each in epv_seg_search_kernel) and the
         //      branch onto the assemble list: one atomic per wave and node reserves both ranges.
         //      A branch with more than 64 segments, or one that finds the lists full, takes the
@@ -404,9 +426,9 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
                   trip0 = trip_b;
                   seg_clean = false;       // the only segment of a dirty branch
                 } else {
-                  const double *hr = list + (size_t)(hrec0 + k) * EPV_HREC;
-                  len = hr[8];
-                  trip0 = (uint32_t)epv_d2u(hr[9]) & 7u;
+                  const double *hr = list + (size_t)(hrec0 + k) * HREC;
+                  len = hr[LEN_AT];
+                  trip0 = (uint32_t)epv_d2u(hr[INFO_AT]) & 7u;
                   seg_clean = (sampled == prev) && (1.0 - hr[7] < (prev ? hr[5] : hr[4]));
                 }
                 if (!seg_clean) {
@@ -440,6 +462,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       }
     }
 
+    P2_MARK(5);
     // ---- 5. hand-over.  A proposal equal to the current path is accepted with probability one
     //         and changes neither the paths nor the cached likelihoods: count it and be done.
     //         Everything else: start states of the proposal's branches into the other buffer,
@@ -470,7 +493,15 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_ACCEPT, shard)], (unsigned long long)__popcll(am));
     }
     pending = pending && !run;
+    P2_MARK(6);
   }
+#ifdef EPV_P2_PROFILE
+  if (epv_lane() == 0) {
+    unsigned long long *row = epv_p2_prof + 8u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % EPV_P2_PROF_ROWS);
+    for (int q = 0; q < 7; ++q) row[q] += t_acc_[q];
+    row[7] += 1ull;
+  }
+#endif
 }
 
 #endif
