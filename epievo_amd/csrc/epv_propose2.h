@@ -181,13 +181,19 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
   const double *s_rates = s_const;
   const double *s_blen = s_const + 20;
 
+  // plane offsets without per-lane 64-bit multiplies (quarter-rate on the vector unit): the buffer
+  // select is a conditional add, the branch stride a wave-uniform product
+  const uint64_t Bn = (uint64_t)B * n, Cn = (uint64_t)S.C * n;
+  const uint64_t mbaseL = (selL ? Bn : 0ull) + (site - 1), mbaseR = (selR ? Bn : 0ull) + (site + 1);
+  const uint64_t mbaseM = (selM ? Bn : 0ull) + site;
+  const uint64_t jbaseL = (selL ? Bn * S.C : 0ull) + (site - 1), jbaseR = (selR ? Bn * S.C : 0ull) + (site + 1);
   uint32_t need_rec = 0, heavy = 0;
   if (valid) {
 #pragma unroll 4
     for (uint32_t b = 0; b < B; ++b) {
-      const uint32_t mL = S.meta[meta_idx(S, selL, b, site - 1)];
-      const uint32_t mR = S.meta[meta_idx(S, selR, b, site + 1)];
-      const uint32_t mM = S.meta[meta_idx(S, selM, b, site)];
+      const uint32_t mL = S.meta[mbaseL + (uint64_t)b * n];
+      const uint32_t mR = S.meta[mbaseR + (uint64_t)b * n];
+      const uint32_t mM = S.meta[mbaseM + (uint64_t)b * n];
       s_meta[(0u * B + b) * 64u + lane] = (epv_meta_t)mL;
       s_meta[(1u * B + b) * 64u + lane] = (epv_meta_t)mR;
       s_meta[(2u * B + b) * 64u + lane] = (epv_meta_t)mM;
@@ -223,8 +229,8 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         const uint32_t K = (cL & EPV_NJ_MASK) + (cR & EPV_NJ_MASK) + 1u;
         if (K < 2u) continue;
         PathRef L, R;
-        L.j = S.jumps + ((uint64_t)selL * B + b) * S.C * n + (site - 1); L.nj = cL & EPV_NJ_MASK; L.init = cL >> EPV_INIT_SHIFT;
-        R.j = S.jumps + ((uint64_t)selR * B + b) * S.C * n + (site + 1); R.nj = cR & EPV_NJ_MASK; R.init = cR >> EPV_INIT_SHIFT;
+        L.j = S.jumps + jbaseL + (uint64_t)b * Cn; L.nj = cL & EPV_NJ_MASK; L.init = cL >> EPV_INIT_SHIFT;
+        R.j = S.jumps + jbaseR + (uint64_t)b * Cn; R.nj = cR & EPV_NJ_MASK; R.init = cR >> EPV_INIT_SHIFT;
         uint32_t trip0 = 4u * L.init + R.init, i = 0, j = 0;
         double seg_start = 0.0;
         double tl = L.nj ? L.j[0] : EPV_INF, tr = R.nj ? R.j[0] : EPV_INF;
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t par = S.parent[node];
         const uint32_t st = (par == 0u) ? root_state : (regA[par * 64u + lane] >> 31);
-        S.meta[meta_idx(S, selM ^ 1u, node - 1u, site)] = (epv_meta_t)(st << EPV_INIT_SHIFT);
+        S.meta[(selM ? 0ull : Bn) + (uint64_t)(node - 1u) * n + site] = (epv_meta_t)(st << EPV_INIT_SHIFT);
       }
       S.prop_flag[tid] = 0u;
     }
