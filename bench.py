@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-leg", action="store_true",
                     help="skip the extra steps in reference-arithmetic mode (profiling runs)")
-    ap.add_argument("--shards-per-gpu", type=int, default=2,
+    ap.add_argument("--shards-per-gpu", type=int, default=3,
                     help="contexts per GPU (epievo_amd.parallel.LocalGroup): their dependent kernels "
                          "overlap; results are bit-identical to 1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -67,6 +67,13 @@ struct epv_ctx {
   uint32_t phase_parity = 0;     // accept lists are double-buffered by phase parity
   int use_seg = -1;              // segment-parallel jump kernels (epv_jumps2.h): -1 = by workload
                                  // (long branches, kbar >= 0.25), EPV_SEG_JUMPS=0/1 forces
+  // fused colour phase (epv_propose2.h, FUSED): one kernel per phase for launches of few waves
+  int use_fused = -1;            // -1 = by launch size (EPV_FUSED_MAX_WAVES), EPV_FUSED_PHASE=0/1 forces
+  uint32_t fused_max_waves = 4096;   // measured on tree.nwk: +46 % at 520 waves, +5 % at 2600, -4 % at 5200 (tools/fused_scan.sh)
+  bool fused = false;            // decided by plan_p2 for the uploaded paths
+  uint32_t fused_lanes = 64;     // sites per wave of the fused phase (64 / 32 / 16: EPV_FUSED_LANES, else by launch size)
+  EpvFused F{};                  // per-wave lists, allocated on first use
+  uint64_t fused_waves = 0;      // waves the lists are allocated for
   uint32_t tasks_per_wave = 0;   // epv_mh_jumps_kernel: lanes of a wave that own a task (0 = by workload)
   double kbar = 0.0;  // mean jumps per (site, branch) of the uploaded paths
   size_t mh_lds = 0;
@@ -113,6 +120,8 @@ void free_paths(epv_ctx *c) {
   dfree(c->S.meta); dfree(c->S.jumps); dfree(c->S.sel); dfree(c->S.tri);
   dfree(c->S.prop_llr); dfree(c->S.prop_flag); dfree(c->S.prop_states); dfree(c->S.tasks); dfree(c->S.alist);
   dfree(c->S.segs); dfree(c->S.segout); dfree(c->S.btasks); dfree(c->S.bfirst);
+  dfree(c->F.segs); dfree(c->F.outs); dfree(c->F.bt); dfree(c->F.bfirst);
+  c->fused_waves = 0;
   dfree(c->d_partial[0]); dfree(c->d_partial[1]);
   c->partial_cap[0] = c->partial_cap[1] = 0;
   c->have_paths = c->have_reset = false;
@@ -191,8 +200,20 @@ int plan_p2(epv_ctx *c) {
   const size_t fixed = shared + per_wave_fixed;
   // one lane's worst case: every branch with 2C+1 segments (records K+1, heavy K)
   const uint64_t worst_rec = (uint64_t)B * (2u * C + 2u), worst_heavy = (uint64_t)B * (2u * C + 1u);
+  // the fused phase: few waves (a launch that leaves SIMDs idle pays one wave chain instead of
+  // three to five), at most 64 segments per branch (the hand-over's bit word), lists for the worst
+  // case of every wave within 4 GB
+  // sites per wave: halve while every SIMD could still get two waves
+  uint32_t f_lanes = 64u;
+  if (const char *e = std::getenv("EPV_FUSED_LANES")) { const int v = std::atoi(e); if (v == 16 || v == 32 || v == 64) f_lanes = (uint32_t)v; }
+  else while (f_lanes > 16u && (c->S.phase_cap + f_lanes / 2u - 1u) / (f_lanes / 2u) <= 2048u) f_lanes /= 2u;
+  const uint64_t phase_waves = (c->S.phase_cap + 63u) / 64u;
+  const uint64_t f_seg_cap = 64ull * B * (2u * C + 1u), f_bt_cap = 64ull * B;
+  const uint64_t f_bytes = (c->S.phase_cap + f_lanes - 1u) / f_lanes * (f_seg_cap * (sizeof(EpvSegTask) + sizeof(EpvSegOut)) + f_bt_cap * 12u);
+  bool fused = c->use_p2 && 2u * C + 1u <= 64u && f_bytes <= (4ull << 30) &&
+               (c->use_fused < 0 ? phase_waves <= c->fused_max_waves : c->use_fused != 0);
   // heavy-segment records: 8 doubles, 10 when the segment-parallel jump kernels read them back
-  const uint64_t hrec = seg_jumps_on(c) ? EPV_HREC : EPV_HREC_SHORT;
+  const uint64_t hrec = (fused || seg_jumps_on(c)) ? EPV_HREC : EPV_HREC_SHORT;
   const uint64_t worst_dbl = 2u * worst_rec + hrec * worst_heavy;
   // typical: K = 1 + Poisson(2 kbar) segments per branch; heavy segments E[K; K >= 2]
   const double lam = 2.0 * c->kbar;
@@ -202,13 +223,18 @@ int plan_p2(epv_ctx *c) {
   const double rec_per_lane = B * (1.0 + lam) + n_internal;     // K per branch, +1 for an internal node's q
   const uint64_t typical_dbl = (uint64_t)(64.0 * (2.0 * rec_per_lane + (double)hrec * B * heavy_per_branch) * p2_margin()) + 64u;
   const uint64_t max_fit = fixed + 64u < 160u * 1024u ? (160u * 1024u - fixed) / 8u : 0u;
-  const uint64_t want = std::max(worst_dbl, typical_dbl);
+  uint64_t want = std::max(worst_dbl, typical_dbl);
+  // the fused phase reuses the pool for the search's cooperative area and then for the accept
+  // stage's accumulators (768 doubles) and meta cache (5 B columns of 64 words)
+  if (fused) want = std::max<uint64_t>(want, std::max<uint64_t>(EPV_COOP_BYTES / 8u, 768u + 80u * (uint64_t)B));
   const bool lds_ok = want <= max_fit && (fixed + want * 8u) * 5u <= 160u * 1024u;   // >= 5 waves per CU
   const bool use_lds = std::getenv("EPV_FORCE_GLOBAL_POOL") ? false
                        : std::getenv("EPV_FORCE_LDS_POOL") ? want <= max_fit : lds_ok;
   if (fixed > 150u * 1024u) return fail(c, EPV_ERR_ARG, "tree too large for the 160 KiB LDS node table");
   c->p2_waves = 1;
   if (const char *e = std::getenv("EPV_P2_WAVES_PER_BLOCK")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) c->p2_waves = (uint32_t)v; }
+  c->fused = fused && use_lds;
+  c->fused_lanes = f_lanes;
   if (use_lds) {
     c->p2_gpool = false;
     c->p2_pool = (uint32_t)((want + 1u) & ~(uint64_t)1u);
@@ -232,6 +258,25 @@ int plan_p2(epv_ctx *c) {
   c->p2_pool = (uint32_t)rows;
   c->p2_list_cap = (uint32_t)list_cap;
   c->p2_lds = shared + c->p2_waves * per_wave_fixed;
+  return EPV_OK;
+}
+
+// per-wave lists of the fused phase, on first use
+int ensure_fused_buffers(epv_ctx *c) {
+  const uint64_t waves = (c->S.phase_cap + c->fused_lanes - 1u) / c->fused_lanes + 4u;
+  const uint64_t seg_cap = 64ull * c->S.B * (2u * c->S.C + 1u), bt_cap = 64ull * c->S.B;
+  if (c->F.segs && c->fused_waves >= waves && c->F.seg_cap == seg_cap && c->F.bt_cap == bt_cap) return EPV_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  dfree(c->F.segs); dfree(c->F.outs); dfree(c->F.bt); dfree(c->F.bfirst);
+  c->fused_waves = 0;
+  HIP_TRY(c, hipMalloc(&c->F.segs, waves * seg_cap * sizeof(EpvSegTask)));
+  HIP_TRY(c, hipMalloc(&c->F.outs, waves * seg_cap * sizeof(EpvSegOut)));
+  HIP_TRY(c, hipMalloc(&c->F.bt, waves * bt_cap * sizeof(unsigned long long)));
+  HIP_TRY(c, hipMalloc(&c->F.bfirst, waves * bt_cap * sizeof(uint32_t)));
+  c->F.seg_cap = (uint32_t)seg_cap;
+  c->F.bt_cap = (uint32_t)bt_cap;
+  c->fused_waves = waves;
   return EPV_OK;
 }
 
@@ -349,16 +394,37 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   // segment-parallel jumps pay on long branches (single branch T = 1: +17 %, every segment is
   // dirty and needs several trials) and cost on short ones (tree.nwk: -12 %, one dirty segment in
   // fourteen branches does not repay the extra hand-over): profiles/r02_ab_seg_jumps.txt
+  static const bool no_cache = std::getenv("EPV_ACCEPT_NO_CACHE") != nullptr;
+  const uint32_t meta_cache = (c->S.B <= 8u && !no_cache) ? 1u : 0u;
+  if (p2 && c->fused) {
+    // the whole phase in one kernel, one wave per 64 sites (see epv_propose2.h)
+    const int frc = ensure_fused_buffers(c);
+    if (frc) return frc;
+    const unsigned pt = 64u * c->p2_waves, per_block = c->fused_lanes * c->p2_waves;
+    const unsigned pb = (unsigned)((threads + per_block - 1u) / per_block);
+    if ((uint64_t)pb * c->p2_waves > c->fused_waves) return fail(c, EPV_ERR_STATE, "fused phase: launch larger than its lists");
+    EpvFused F = c->F;
+    F.meta_cache = meta_cache;
+    F.lanes = c->fused_lanes;
+    hipLaunchKernelGGL((epv_mh_propose2_kernel<false, true, true>), dim3(pb), dim3(pt), c->p2_lds, c->stream, c->S,
+                       (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
+                       c->p2_pool, c->p2_list_cap, 0u, c->d_counters, (double *)nullptr, c->d_segtab, F);
+    if (c->timing) HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipGetLastError());
+    if (c->halo_mode) ++c->phases_used;
+    return EPV_OK;
+  }
   const uint32_t seg_mode = (p2 && seg_jumps_on(c)) ? 1u : 0u;
   if (seg_mode) { const int src = ensure_seg_buffers(c); if (src) return src; }
   if (p2) {
     list_mode = 1u + (c->phase_parity & 1u);
     const unsigned pt = 64u * c->p2_waves, pb = (unsigned)((threads + pt - 1u) / pt);
-    auto kern = c->p2_gpool ? (seg_mode ? epv_mh_propose2_kernel<true, true> : epv_mh_propose2_kernel<true, false>)
-                            : (seg_mode ? epv_mh_propose2_kernel<false, true> : epv_mh_propose2_kernel<false, false>);
+    auto kern = c->p2_gpool ? (seg_mode ? epv_mh_propose2_kernel<true, true, false> : epv_mh_propose2_kernel<true, false, false>)
+                            : (seg_mode ? epv_mh_propose2_kernel<false, true, false> : epv_mh_propose2_kernel<false, false, false>);
     hipLaunchKernelGGL(kern, dim3(pb), dim3(pt), c->p2_lds, c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
                        (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->p2_pool, c->p2_list_cap,
-                       c->phase_parity & 1u, c->d_counters, c->p2_gpool ? c->d_gpool2 : (double *)nullptr, c->d_segtab);
+                       c->phase_parity & 1u, c->d_counters, c->p2_gpool ? c->d_gpool2 : (double *)nullptr, c->d_segtab,
+                       EpvFused{});
     ++c->phase_parity;
   } else {
     auto kern = c->mh_gpool ? (refq ? epv_mh_propose_kernel<true, true> : epv_mh_propose_kernel<true, false>)
@@ -399,8 +465,6 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   }
   // meta cache of the accept kernel: 5 columns x B words per lane in LDS while that stays small
   // (B <= 8: 20 KB per block next to the 24 KB of accumulators)
-  static const bool no_cache = std::getenv("EPV_ACCEPT_NO_CACHE") != nullptr;
-  const uint32_t meta_cache = (c->S.B <= 8u && !no_cache) ? 1u : 0u;
   const size_t acc_lds = const_lds_bytes(c->S.N) + (meta_cache ? (size_t)5u * c->S.B * 256u * sizeof(epv_meta_t) : 0u);
   if (list_mode) {
     // the listed sites (proposal differs from the current path) per shard: typically ~30 % of the
@@ -463,6 +527,8 @@ EPV_API epv_ctx *epv_create(int device_id) {
   c->device = device_id;
   if (const char *e = std::getenv("EPV_PROPOSE_V1")) c->use_p2 = std::atoi(e) == 0;
   if (const char *e = std::getenv("EPV_SEG_JUMPS")) c->use_seg = std::atoi(e) != 0 ? 1 : 0;
+  if (const char *e = std::getenv("EPV_FUSED_PHASE")) c->use_fused = std::atoi(e) != 0 ? 1 : 0;
+  if (const char *e = std::getenv("EPV_FUSED_MAX_WAVES")) { const long v = std::atol(e); if (v >= 0) c->fused_max_waves = (uint32_t)v; }
   if (const char *e = std::getenv("EPV_TASKS_PER_WAVE")) {  // tuning knob
     const int v = std::atoi(e);
     if (v >= 1 && v <= 64) c->tasks_per_wave = (uint32_t)v;
@@ -476,13 +542,15 @@ EPV_API epv_ctx *epv_create(int device_id) {
     return nullptr;
   }
   // the MH kernel asks for more dynamic LDS than the 64 KiB default
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, false>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, true>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<true, false>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<true, true>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<true, false, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<true, true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1445,13 +1513,13 @@ EPV_API int epv_get_counters(epv_ctx *c, epv_counters *out) {
 }
 
 #ifdef EPV_P2_PROFILE
-// sums over the per-wave rows: out[0..6] section cycles, out[7] waves
+// sums over the per-wave rows: out[0..14] section cycles, out[15] waves
 EPV_API int epv_debug_p2_profile(unsigned long long *out) {
-  std::vector<unsigned long long> rows(8u * EPV_P2_PROF_ROWS);
+  std::vector<unsigned long long> rows(16u * EPV_P2_PROF_ROWS);
   if (hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(epv_p2_prof), rows.size() * sizeof(unsigned long long)) != hipSuccess) return 1;
-  for (int q = 0; q < 8; ++q) out[q] = 0;
+  for (int q = 0; q < 16; ++q) out[q] = 0;
   for (size_t r = 0; r < EPV_P2_PROF_ROWS; ++r)
-    for (int q = 0; q < 8; ++q) out[q] += rows[8u * r + q];
+    for (int q = 0; q < 16; ++q) out[q] += rows[16u * r + q];
   return 0;
 }
 #endif

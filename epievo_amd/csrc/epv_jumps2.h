@@ -33,29 +33,23 @@
 #define EPV_SEARCH_WAVES 2
 #endif
 
-__global__ __launch_bounds__(256, EPV_SEARCH_WAVES) void epv_seg_search_kernel(EpvDev S, uint32_t seed_lo,
-                                                                               uint32_t seed_hi, uint32_t sweep,
-                                                                               unsigned long long *counters) {
-  extern __shared__ __attribute__((aligned(16))) double s_mem[];
-  // per-wave cooperative-search area: task slots by rank and per-lane trial results
-  __shared__ double c_len_[4][64], c_r0_[4][64], c_r1_[4][64], c_trunc_[4][64], c_tj_[4][64 * 2];
-  __shared__ uint32_t c_misc_[4][64], c_gsite_[4][64], c_tbase_[4][64], c_nk_[4][64], c_res_[4][64],
-      c_tw_[4][64], c_mm_[4][64];
-  stage_constants(S, s_mem);
-  const double *s_rates = s_mem;
-  const uint32_t wave = threadIdx.x >> 6;
+// cooperative-search area of ONE wave (LDS): task slots by rank and per-lane trial results
+struct EpvCoop {
+  double *len, *r0, *r1, *trunc, *tj;     // [64] each, tj [128]
+  uint32_t *misc, *gsite, *tbase, *nk, *res, *tw, *mm;   // [64] each
+};
+#define EPV_COOP_BYTES (64u * (6u * 8u + 7u * 4u))
+
+// the wave's share of a segment list: entries base_first + lane, + stride, ... below n_seg
+__device__ __forceinline__ void epv_seg_search_wave(const EpvDev &S, const double *s_rates, const EpvCoop &W,
+                                                    const EpvSegTask *segs, EpvSegOut *outs, uint64_t n_seg,
+                                                    uint64_t base_first, uint64_t stride, uint32_t seed_lo,
+                                                    uint32_t seed_hi, uint32_t sweep, bool nielsen) {
   const int lane = epv_lane();
-  double *c_len = c_len_[wave], *c_r0 = c_r0_[wave], *c_r1 = c_r1_[wave], *c_trunc = c_trunc_[wave], *c_tj = c_tj_[wave];
-  uint32_t *c_misc = c_misc_[wave], *c_gsite = c_gsite_[wave], *c_tbase = c_tbase_[wave], *c_nk = c_nk_[wave],
-           *c_res = c_res_[wave], *c_tw = c_tw_[wave], *c_mm = c_mm_[wave];
-  const bool nielsen = !(S.flags & EPV_FLAG_FORWARD_REJECTION);
-  const uint32_t shard = blockIdx.y;
-  const unsigned long long packed = counters[EPV_CNT_IDX(EPV_CNT_SEG, shard)];
-  const uint64_t n_seg = (packed & 0xffffffffull) < S.seg_cap ? (uint64_t)(packed & 0xffffffffull) : S.seg_cap;
-  const EpvSegTask *segs = S.segs + (uint64_t)shard * S.seg_cap;
-  EpvSegOut *outs = S.segout + (uint64_t)shard * S.seg_cap;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x + wave * 64u; base < n_seg; base += stride) {
+  double *c_len = W.len, *c_r0 = W.r0, *c_r1 = W.r1, *c_trunc = W.trunc, *c_tj = W.tj;
+  uint32_t *c_misc = W.misc, *c_gsite = W.gsite, *c_tbase = W.tbase, *c_nk = W.nk, *c_res = W.res, *c_tw = W.tw,
+           *c_mm = W.mm;
+  for (uint64_t base = base_first; base < n_seg; base += stride) {
     const uint64_t i = base + (unsigned)lane;
     EpvSegTask t;
     t.w0 = 0ull; t.len = -1.0; t.start = 0.0; t.w3 = 0ull;
@@ -139,6 +133,77 @@ __global__ __launch_bounds__(256, EPV_SEARCH_WAVES) void epv_seg_search_kernel(E
   }
 }
 
+__global__ __launch_bounds__(256, EPV_SEARCH_WAVES) void epv_seg_search_kernel(EpvDev S, uint32_t seed_lo,
+                                                                               uint32_t seed_hi, uint32_t sweep,
+                                                                               unsigned long long *counters) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  // per-wave cooperative-search area: task slots by rank and per-lane trial results
+  __shared__ double c_len_[4][64], c_r0_[4][64], c_r1_[4][64], c_trunc_[4][64], c_tj_[4][64 * 2];
+  __shared__ uint32_t c_misc_[4][64], c_gsite_[4][64], c_tbase_[4][64], c_nk_[4][64], c_res_[4][64],
+      c_tw_[4][64], c_mm_[4][64];
+  stage_constants(S, s_mem);
+  const double *s_rates = s_mem;
+  const uint32_t wave = threadIdx.x >> 6;
+  EpvCoop W;
+  W.len = c_len_[wave]; W.r0 = c_r0_[wave]; W.r1 = c_r1_[wave]; W.trunc = c_trunc_[wave]; W.tj = c_tj_[wave];
+  W.misc = c_misc_[wave]; W.gsite = c_gsite_[wave]; W.tbase = c_tbase_[wave]; W.nk = c_nk_[wave];
+  W.res = c_res_[wave]; W.tw = c_tw_[wave]; W.mm = c_mm_[wave];
+  const bool nielsen = !(S.flags & EPV_FLAG_FORWARD_REJECTION);
+  const uint32_t shard = blockIdx.y;
+  const unsigned long long packed = counters[EPV_CNT_IDX(EPV_CNT_SEG, shard)];
+  const uint64_t n_seg = (packed & 0xffffffffull) < S.seg_cap ? (uint64_t)(packed & 0xffffffffull) : S.seg_cap;
+  const EpvSegTask *segs = S.segs + (uint64_t)shard * S.seg_cap;
+  EpvSegOut *outs = S.segout + (uint64_t)shard * S.seg_cap;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  epv_seg_search_wave(S, s_rates, W, segs, outs, n_seg, (uint64_t)blockIdx.x * blockDim.x + wave * 64u, stride, seed_lo,
+                      seed_hi, sweep, nielsen);
+}
+
+// one dirty branch (task word bt, its segments at segs/outs[first ..]): results in order into the
+// proposal; a capacity overflow flags the site (phase index tid)
+__device__ __forceinline__ void epv_seg_assemble_one(const EpvDev &S, const double *s_rates, const EpvSegTask *segs,
+                                                     const EpvSegOut *outs, unsigned long long bt, uint64_t first,
+                                                     uint64_t s0, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
+                                                     bool nielsen) {
+  const uint64_t n = S.n;
+  const uint32_t B = S.B, C = S.C;
+  const uint64_t site = bt & 0xffffffffffull;
+  const uint32_t b = (uint32_t)(bt >> 40) & 4095u, nds = (uint32_t)(bt >> 52) & 127u, end_state = (uint32_t)(bt >> 59) & 1u;
+  const uint32_t selP = S.sel[site] ^ 1u;
+  epv_meta_t *meta = S.meta + meta_idx(S, selP, b, site);
+  double *dst = S.jumps + ((uint64_t)selP * B + b) * C * n + site;
+  const uint32_t start_state = (uint32_t)(*meta >> EPV_INIT_SHIFT);
+  uint32_t cnt = 0;
+  bool ovf = false;
+  for (uint32_t q = 0; q < nds && !ovf; ++q) {
+    const EpvSegOut o = outs[first + q];
+    const uint32_t room = C - cnt;
+    if (o.maxm > room) { ovf = true; break; }     // some trial up to the winner needed more slots
+    if (o.cnt <= 2u) {
+      if (o.cnt >= 1u) dst[(uint64_t)cnt * n] = o.j0;
+      if (o.cnt >= 2u) dst[(uint64_t)(cnt + 1u) * n] = o.j1;
+    } else {                                      // replay the winning trial into the path
+      const EpvSegTask t = segs[first + q];
+      const uint32_t gsite = (uint32_t)(S.g0 + site);
+      const uint32_t node = (uint32_t)(t.w0 >> 40) & 4095u, k = (uint32_t)(t.w0 >> 52);
+      const uint32_t prev = (uint32_t)t.w3 & 1u, sampled = (uint32_t)(t.w3 >> 1) & 1u, trip0 = (uint32_t)(t.w3 >> 2) & 7u;
+      const double r0 = s_rates[trip0], r1 = s_rates[trip0 | 2u];
+      double trunc = 0.0;
+      if (sampled != prev) trunc = 1.0 - epv_exp(-(prev ? r1 : r0) * t.len);
+      const double u0 = first_draw(seed_lo, seed_hi, gsite, sweep, node, k, o.tstar);
+      uint32_t nj2 = 0;
+      run_trial(seed_lo, seed_hi, gsite, sweep, node, k, o.tstar, u0, prev, sampled, t.len, r0, r1, 0.0, 0.0, trunc,
+                room, dst + (uint64_t)cnt * n, n, 0xffffffffu, t.start, nj2, nielsen);
+    }
+    cnt += o.cnt;
+  }
+  if (ovf) {
+    cnt = (start_state ^ end_state) & 1u;         // keep the end-state parity; the proposal is rejected
+    S.prop_flag[(site - s0) / 3u] = 1u;
+  }
+  *meta = (epv_meta_t)((start_state << EPV_INIT_SHIFT) | cnt);
+}
+
 // one lane per dirty branch: the results of its dirty segments, in order, into the proposal
 __global__ __launch_bounds__(256) void epv_seg_assemble_kernel(EpvDev S, uint32_t seed_lo, uint32_t seed_hi,
                                                                uint32_t sweep, uint64_t s0,
@@ -152,47 +217,11 @@ __global__ __launch_bounds__(256) void epv_seg_assemble_kernel(EpvDev S, uint32_
   const uint64_t n_b = (packed >> 32) < S.btask_cap ? (uint64_t)(packed >> 32) : S.btask_cap;
   const EpvSegTask *segs = S.segs + (uint64_t)shard * S.seg_cap;
   const EpvSegOut *outs = S.segout + (uint64_t)shard * S.seg_cap;
-  const uint64_t n = S.n;
-  const uint32_t B = S.B, C = S.C;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_b; i += (uint64_t)gridDim.x * blockDim.x) {
     const unsigned long long bt = S.btasks[(uint64_t)shard * S.btask_cap + i];
     if (bt == ~0ull) continue;                      // blanked: the branch went to the sequential kernel
-    const uint64_t site = bt & 0xffffffffffull;
-    const uint32_t b = (uint32_t)(bt >> 40) & 4095u, nds = (uint32_t)(bt >> 52) & 127u, end_state = (uint32_t)(bt >> 59) & 1u;
-    const uint64_t first = S.bfirst[(uint64_t)shard * S.btask_cap + i];
-    const uint32_t selP = S.sel[site] ^ 1u;
-    epv_meta_t *meta = S.meta + meta_idx(S, selP, b, site);
-    double *dst = S.jumps + ((uint64_t)selP * B + b) * C * n + site;
-    const uint32_t start_state = (uint32_t)(*meta >> EPV_INIT_SHIFT);
-    uint32_t cnt = 0;
-    bool ovf = false;
-    for (uint32_t q = 0; q < nds && !ovf; ++q) {
-      const EpvSegOut o = outs[first + q];
-      const uint32_t room = C - cnt;
-      if (o.maxm > room) { ovf = true; break; }     // some trial up to the winner needed more slots
-      if (o.cnt <= 2u) {
-        if (o.cnt >= 1u) dst[(uint64_t)cnt * n] = o.j0;
-        if (o.cnt >= 2u) dst[(uint64_t)(cnt + 1u) * n] = o.j1;
-      } else {                                      // replay the winning trial into the path
-        const EpvSegTask t = segs[first + q];
-        const uint32_t gsite = (uint32_t)(S.g0 + site);
-        const uint32_t node = (uint32_t)(t.w0 >> 40) & 4095u, k = (uint32_t)(t.w0 >> 52);
-        const uint32_t prev = (uint32_t)t.w3 & 1u, sampled = (uint32_t)(t.w3 >> 1) & 1u, trip0 = (uint32_t)(t.w3 >> 2) & 7u;
-        const double r0 = s_rates[trip0], r1 = s_rates[trip0 | 2u];
-        double trunc = 0.0;
-        if (sampled != prev) trunc = 1.0 - epv_exp(-(prev ? r1 : r0) * t.len);
-        const double u0 = first_draw(seed_lo, seed_hi, gsite, sweep, node, k, o.tstar);
-        uint32_t nj2 = 0;
-        run_trial(seed_lo, seed_hi, gsite, sweep, node, k, o.tstar, u0, prev, sampled, t.len, r0, r1, 0.0, 0.0, trunc,
-                  room, dst + (uint64_t)cnt * n, n, 0xffffffffu, t.start, nj2, nielsen);
-      }
-      cnt += o.cnt;
-    }
-    if (ovf) {
-      cnt = (start_state ^ end_state) & 1u;         // keep the end-state parity; the proposal is rejected
-      S.prop_flag[(site - s0) / 3u] = 1u;
-    }
-    *meta = (epv_meta_t)((start_state << EPV_INIT_SHIFT) | cnt);
+    epv_seg_assemble_one(S, s_rates, segs, outs, bt, S.bfirst[(uint64_t)shard * S.btask_cap + i], s0, seed_lo, seed_hi,
+                         sweep, nielsen);
   }
 }
 

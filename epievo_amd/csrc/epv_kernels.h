@@ -680,7 +680,6 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
   }
 }
 
-#include "epv_propose2.h"
 
 // =========================================================================
 //  exact forward rejection (EndCondSampling.cpp:466-509) for the dirty (site, branch)
@@ -910,6 +909,75 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
 
 #include "epv_jumps2.h"
 
+// acceptance of ONE site's proposal (the lane's): bit 0 = accepted and counted (own site), bit 1 =
+// rejected for capacity.  s_mc = this lane's column of the meta cache (element (col * B + b) at
+// [(col * B + b) * mc_stride]) when meta_cache != 0.
+__device__ __forceinline__ uint32_t epv_accept_site(const EpvDev &S, const double *s_const, const double *s_blen,
+                                                    epv_meta_t *s_mc, uint32_t mc_stride, uint32_t meta_cache,
+                                                    AccLds &A, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
+                                                    uint64_t tid, uint64_t site, uint64_t own_first, uint64_t own_last) {
+  bool accepted = false, overflowed = false;
+  const uint32_t selL = S.sel[site - 1], selM = S.sel[site], selR = S.sel[site + 1];
+  const uint32_t gsite = (uint32_t)(S.g0 + site);
+  const bool ovf = S.prop_flag[tid] != 0;
+  double llh_l = S.tri[site - 1];
+  double llh_m = S.tri[site];
+  double llh_r = S.tri[site + 1];
+  double llr = (S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO) ? S.prop_llr[tid] : 0.0;
+  const double llh_l_orig = llh_l, llh_r_orig = llh_r;
+  if (!ovf) {
+    // the three triples centred at site-1, site, site+1 with the proposal standing in
+    // for this site's column (one loop, so merge3 is instantiated once)
+    const uint32_t selP = selM ^ 1u;
+    const uint64_t g = S.g0 + site;
+    const bool hasLL = g > 1u, hasRR = g < S.n_global - 2u;
+    const uint32_t selLL = hasLL ? S.sel[site - 2] : 0u;
+    const uint32_t selRR = hasRR ? S.sel[site + 2] : 0u;
+    if (meta_cache) {
+      // all the meta words of the five columns in one batch of independent loads
+      const uint32_t B = S.B;
+#pragma unroll 4
+      for (uint32_t b = 0; b < B; ++b) {
+        const epv_meta_t m0 = hasLL ? S.meta[meta_idx(S, selLL, b, site - 2)] : (epv_meta_t)0;
+        const epv_meta_t m1 = S.meta[meta_idx(S, selL, b, site - 1)];
+        const epv_meta_t m2 = S.meta[meta_idx(S, selP, b, site)];
+        const epv_meta_t m3 = S.meta[meta_idx(S, selR, b, site + 1)];
+        const epv_meta_t m4 = hasRR ? S.meta[meta_idx(S, selRR, b, site + 2)] : (epv_meta_t)0;
+        s_mc[(0u * B + b) * mc_stride] = m0;
+        s_mc[(1u * B + b) * mc_stride] = m1;
+        s_mc[(2u * B + b) * mc_stride] = m2;
+        s_mc[(3u * B + b) * mc_stride] = m3;
+        s_mc[(4u * B + b) * mc_stride] = m4;
+      }
+    }
+    for (int w = 0; w < 3; ++w) {
+      if ((w == 0 && !hasLL) || (w == 2 && !hasRR)) continue;
+      const uint64_t c = site - 1u + (uint64_t)w;
+      const uint32_t bl = (w == 0) ? selLL : (w == 1) ? selL : selP;
+      const uint32_t bm = (w == 0) ? selL : (w == 1) ? selP : selR;
+      const uint32_t br = (w == 0) ? selP : (w == 1) ? selR : selRR;
+      const double v = meta_cache
+                           ? triple_llh_cached(S, s_const, s_blen, s_mc, mc_stride, (uint32_t)w, bl, c - 1u, (uint32_t)w + 1u,
+                                               bm, c, (uint32_t)w + 2u, br, c + 1u, A)
+                           : triple_llh(S, s_const, s_blen, bl, c - 1u, bm, c, br, c + 1u, A);
+      if (w == 0) llh_l = v; else if (w == 1) llh_m = v; else llh_r = v;
+    }
+  }
+  llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
+  const double u = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, 0u, 0u, 0u, 0u).d0;
+  bool acc = (llr >= 0.0) || (u < epv_exp(llr));
+  if (ovf) { acc = false; overflowed = true; }
+  if (acc) {
+    S.sel[site] = (uint8_t)(selM ^ 1u);
+    S.tri[site - 1] = llh_l;
+    S.tri[site] = llh_m;
+    S.tri[site + 1] = llh_r;
+    // redundant updates of halo columns (site-sharded runs) are not counted
+    accepted = site >= own_first && site <= own_last;
+  }
+  return (accepted ? 1u : 0u) | (overflowed ? 2u : 0u);
+}
+
 // =========================================================================
 //  acceptance (log_accept_rate SingleSiteSampler.cpp:396-433, Metropolis_Hastings_site
 //  :510-533): one lane per site of the colour, after epv_mh_propose_kernel has written
@@ -957,64 +1025,9 @@ __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
   const uint64_t site = s0 + 3u * tid;
   bool accepted = false, overflowed = false;
   if (have && site <= last) {
-    const uint32_t selL = S.sel[site - 1], selM = S.sel[site], selR = S.sel[site + 1];
-    const uint32_t gsite = (uint32_t)(S.g0 + site);
-    const bool ovf = S.prop_flag[tid] != 0;
-    double llh_l = S.tri[site - 1];
-    double llh_m = S.tri[site];
-    double llh_r = S.tri[site + 1];
-    double llr = (S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO) ? S.prop_llr[tid] : 0.0;
-    const double llh_l_orig = llh_l, llh_r_orig = llh_r;
-    if (!ovf) {
-      // the three triples centred at site-1, site, site+1 with the proposal standing in
-      // for this site's column (one loop, so merge3 is instantiated once)
-      const uint32_t selP = selM ^ 1u;
-      const uint64_t g = S.g0 + site;
-      const bool hasLL = g > 1u, hasRR = g < S.n_global - 2u;
-      const uint32_t selLL = hasLL ? S.sel[site - 2] : 0u;
-      const uint32_t selRR = hasRR ? S.sel[site + 2] : 0u;
-      if (meta_cache) {
-        // all the meta words of the five columns in one batch of independent loads
-        const uint32_t B = S.B;
-#pragma unroll 4
-        for (uint32_t b = 0; b < B; ++b) {
-          const epv_meta_t m0 = hasLL ? S.meta[meta_idx(S, selLL, b, site - 2)] : (epv_meta_t)0;
-          const epv_meta_t m1 = S.meta[meta_idx(S, selL, b, site - 1)];
-          const epv_meta_t m2 = S.meta[meta_idx(S, selP, b, site)];
-          const epv_meta_t m3 = S.meta[meta_idx(S, selR, b, site + 1)];
-          const epv_meta_t m4 = hasRR ? S.meta[meta_idx(S, selRR, b, site + 2)] : (epv_meta_t)0;
-          s_mc[(0u * B + b) * 256u] = m0;
-          s_mc[(1u * B + b) * 256u] = m1;
-          s_mc[(2u * B + b) * 256u] = m2;
-          s_mc[(3u * B + b) * 256u] = m3;
-          s_mc[(4u * B + b) * 256u] = m4;
-        }
-      }
-      for (int w = 0; w < 3; ++w) {
-        if ((w == 0 && !hasLL) || (w == 2 && !hasRR)) continue;
-        const uint64_t c = site - 1u + (uint64_t)w;
-        const uint32_t bl = (w == 0) ? selLL : (w == 1) ? selL : selP;
-        const uint32_t bm = (w == 0) ? selL : (w == 1) ? selP : selR;
-        const uint32_t br = (w == 0) ? selP : (w == 1) ? selR : selRR;
-        const double v = meta_cache
-                             ? triple_llh_cached(S, s_const, s_blen, s_mc, 256u, (uint32_t)w, bl, c - 1u, (uint32_t)w + 1u,
-                                                 bm, c, (uint32_t)w + 2u, br, c + 1u, A)
-                             : triple_llh(S, s_const, s_blen, bl, c - 1u, bm, c, br, c + 1u, A);
-        if (w == 0) llh_l = v; else if (w == 1) llh_m = v; else llh_r = v;
-      }
-    }
-    llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
-    const double u = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, 0u, 0u, 0u, 0u).d0;
-    bool acc = (llr >= 0.0) || (u < epv_exp(llr));
-    if (ovf) { acc = false; overflowed = true; }
-    if (acc) {
-      S.sel[site] = (uint8_t)(selM ^ 1u);
-      S.tri[site - 1] = llh_l;
-      S.tri[site] = llh_m;
-      S.tri[site + 1] = llh_r;
-      // redundant updates of halo columns (site-sharded runs) are not counted
-      accepted = site >= own_first && site <= own_last;
-    }
+    const uint32_t r = epv_accept_site(S, s_const, s_blen, s_mc, 256u, meta_cache, A, seed_lo, seed_hi, sweep, tid, site,
+                                       own_first, own_last);
+    accepted = r & 1u; overflowed = (r & 2u) != 0u;
   }
   const unsigned long long am = __ballot(accepted), om = __ballot(overflowed);
   if (lane == 0) {
@@ -1038,6 +1051,9 @@ __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
     counters[EPV_CNT_IDX(EPV_CNT_SEG, threadIdx.x)] = 0ull;
   }
 }
+
+// the second proposal kernel; its fused variant runs the search, assembly and acceptance above
+#include "epv_propose2.h"
 
 // =========================================================================
 //  initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device: every

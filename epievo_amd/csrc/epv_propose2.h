@@ -118,16 +118,34 @@ __device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long l
 // one row per wave and plain stores: atomics on shared counters would serialise the waves and
 // show up as waiting time wherever the compiler put the next s_waitcnt
 #define EPV_P2_PROF_ROWS 8192
-__device__ unsigned long long epv_p2_prof[8 * EPV_P2_PROF_ROWS];
+__device__ unsigned long long epv_p2_prof[16 * EPV_P2_PROF_ROWS];
 #define P2_MARK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc_[i] += t_ - t_prev_; t_prev_ = t_; } while (0)
 #else
 #define P2_MARK(i) do {} while (0)
 #endif
-template <bool GPOOL, bool SEG>
+// FUSED (small launches, LDS pool only): the wave keeps the segment and branch lists of ITS 64 sites
+// in a private region of global memory and runs the whole colour phase itself -- proposal, then
+// the segment search, the assembly of its dirty branches and the acceptance of its sites with the
+// device functions of epv_seg_search_kernel / epv_seg_assemble_kernel / epv_mh_accept_kernel.
+// Every site of a colour is independent of the others, so nothing in a phase needs more than a
+// wave; what the separate kernels buy is dense lanes, and what they cost is one ~20 us wave chain
+// per kernel, which is all there is to pay when a launch has fewer waves than the chip has SIMDs.
+struct EpvFused {
+  EpvSegTask *segs;            // [waves][seg_cap]
+  EpvSegOut *outs;             // [waves][seg_cap]
+  unsigned long long *bt;      // [waves][bt_cap]
+  uint32_t *bfirst;            // [waves][bt_cap]
+  uint32_t seg_cap, bt_cap;    // per wave: 64 B (2C+1) and 64 B -- the worst case, so nothing overflows
+  uint32_t meta_cache;         // accept stage: meta words of the five columns in LDS (B <= 8)
+  uint32_t lanes;              // sites per wave
+};
+
+template <bool GPOOL, bool SEG, bool FUSED>
 __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first,
     uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t pool_dbl, uint32_t list_cap,
-    uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab) {
+    uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab, EpvFused F) {
+  static_assert(!FUSED || (SEG && !GPOOL), "the fused phase emits segments and keeps its pool in LDS");
   // SEG: true = dirty SEGMENTS go to the segment-parallel jump kernels (epv_jumps2.h); 0 = dirty
   // branches go to epv_mh_jumps_kernel's bucketed lists
   // pool_dbl: LDS pool -- doubles per wave; GPOOL -- record ROWS per lane (list_cap heavy records
@@ -135,7 +153,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   constexpr uint32_t HREC = SEG ? EPV_HREC : EPV_HREC_SHORT, LEN_AT = HREC - 2u, INFO_AT = HREC - 1u;
 #ifdef EPV_P2_PROFILE
-  unsigned long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_prev_ = __builtin_readcyclecounter();
 #endif
   const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
@@ -164,9 +182,13 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
                        : s_wave + regA_dbl + mc_dbl;
   const uint64_t gfirst = S.g0 + first;
   const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
-  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // FUSED: F.lanes (64, 32 or 16) sites per wave -- fewer sites, hence fewer search rounds, per wave
+  // when that still leaves SIMDs idle; the other lanes only help in the cooperative stages
+  const uint32_t lpw = FUSED ? F.lanes : 64u;
+  const uint64_t tid = FUSED ? ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave_id) * lpw + (uint32_t)(threadIdx.x & 63u)
+                             : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t site = s0 + 3u * tid;
-  const bool valid = site <= last;
+  const bool valid = site <= last && (threadIdx.x & 63u) < lpw;
   const uint64_t n = S.n;
   const uint32_t B = S.B;
   const uint32_t gsite = (uint32_t)(S.g0 + site);
@@ -204,6 +226,10 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
   }
 
   P2_MARK(0);
+  // FUSED: lengths of the wave's private lists (wave-uniform), and which lanes' sites await acceptance
+  uint32_t f_nseg = 0u, f_nbt = 0u;
+  bool f_listed = false;
+  const uint64_t f_wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave_id;
   bool pending = valid;
   while (__any(pending)) {
     const uint32_t wantR = pending ? need_rec : 0u, wantH = pending ? heavy : 0u;
@@ -407,18 +433,26 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         const uint32_t totS = __shfl(inclS, 63), totB = __shfl(inclB, 63);
         if (totB) {
           const uint32_t shard = my_shard;
-          unsigned long long base = 0ull;
-          if (lane == 0)
-            base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_SEG, shard)],
-                             (unsigned long long)totS | ((unsigned long long)totB << 32));
-          const uint32_t bS = __shfl((uint32_t)base, 0), bB = __shfl((uint32_t)(base >> 32), 0);
+          uint32_t bS, bB;
+          if (FUSED) {
+            bS = f_nseg; bB = f_nbt;
+            f_nseg += totS; f_nbt += totB;
+          } else {
+            unsigned long long base = 0ull;
+            if (lane == 0)
+              base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_SEG, shard)],
+                               (unsigned long long)totS | ((unsigned long long)totB << 32));
+            bS = __shfl((uint32_t)base, 0); bB = __shfl((uint32_t)(base >> 32), 0);
+          }
           if (cand) {
             const uint64_t i0 = (uint64_t)bS + (inclS - wS), j0 = (uint64_t)bB + (inclB - 1u);
-            EpvSegTask *segs = S.segs + (uint64_t)shard * S.seg_cap;
-            if (i0 + nds <= S.seg_cap && j0 < S.btask_cap) {
-              S.btasks[(uint64_t)shard * S.btask_cap + j0] =
-                  site | ((unsigned long long)b << 40) | ((unsigned long long)nds << 52) | ((unsigned long long)end_b << 59);
-              S.bfirst[(uint64_t)shard * S.btask_cap + j0] = (uint32_t)i0;
+            EpvSegTask *segs = FUSED ? F.segs + f_wave * F.seg_cap : S.segs + (uint64_t)shard * S.seg_cap;
+            unsigned long long *btl = FUSED ? F.bt + f_wave * F.bt_cap : S.btasks + (uint64_t)shard * S.btask_cap;
+            uint32_t *bfl = FUSED ? F.bfirst + f_wave * F.bt_cap : S.bfirst + (uint64_t)shard * S.btask_cap;
+            const uint64_t seg_room = FUSED ? F.seg_cap : S.seg_cap, bt_room = FUSED ? F.bt_cap : S.btask_cap;
+            if (i0 + nds <= seg_room && j0 < bt_room) {
+              btl[j0] = site | ((unsigned long long)b << 40) | ((unsigned long long)nds << 52) | ((unsigned long long)end_b << 59);
+              bfl[j0] = (uint32_t)i0;
               uint32_t prev = st_b;
               double tp = 0.0;     // running sum of the segment lengths (SingleSiteSampler.cpp:218)
               uint64_t at = i0;
@@ -451,18 +485,18 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
               old_list = false;
             } else {
               // no room: blank what this lane reserved inside the lists, fall back
-              for (uint64_t i = i0; i < i0 + nds && i < S.seg_cap; ++i) segs[i].len = -1.0;
-              if (j0 < S.btask_cap) S.btasks[(uint64_t)shard * S.btask_cap + j0] = ~0ull;
+              for (uint64_t i = i0; i < i0 + nds && i < seg_room; ++i) segs[i].len = -1.0;
+              if (j0 < bt_room) btl[j0] = ~0ull;
             }
           }
         }
       }
-      if (old_list) {
+      if (!FUSED && old_list) {      // (the fused phase's lists hold the worst case: never taken there)
         dirty |= 1ull << (b & 63u);
         if (Kb == 2u || Kb >= 4u) multi |= 1ull << (b & 63u);   // four buckets by segment count
         if (Kb >= 3u) deep |= 1ull << (b & 63u);
       }
-      if ((b & 63u) == 63u || node + 1u == S.N) {
+      if (!FUSED && ((b & 63u) == 63u || node + 1u == S.N)) {
         epv_flush_tasks(S, counters, dirty, multi, deep, b, site, lane, my_shard);
         dirty = multi = deep = 0ull;
       }
@@ -484,7 +518,8 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
     }
     {
       const uint32_t shard = my_shard;
-      const unsigned long long lm = __ballot(to_list);
+      f_listed = f_listed || to_list;
+      const unsigned long long lm = FUSED ? 0ull : __ballot(to_list);
       if (lm) {
         unsigned long long base = 0ull;
         if (lane == 0)
@@ -501,11 +536,56 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
     pending = pending && !run;
     P2_MARK(6);
   }
+  if (FUSED) {
+    // the pool is free now: the search's cooperative area, then the accept stage's accumulators
+    // and meta cache, are carved from it (plan_p2 sizes it for both)
+    const bool nielsen = !(S.flags & EPV_FLAG_FORWARD_REJECTION);
+    const EpvSegTask *segs = F.segs + f_wave * F.seg_cap;
+    EpvSegOut *outs = F.outs + f_wave * F.seg_cap;
+    // lists, start states and flags pass between the lanes of THIS wave through global memory: a
+    // workgroup-scope fence (wait for the stores; one CU, one vector L1) is enough -- an agent-scope
+    // one writes back and invalidates the XCD's L2, ~30 us each here
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (f_nseg) {
+      EpvCoop W;
+      W.len = pool; W.r0 = pool + 64; W.r1 = pool + 128; W.trunc = pool + 192; W.tj = pool + 256;
+      uint32_t *u = reinterpret_cast<uint32_t *>(pool + 384);
+      W.misc = u; W.gsite = u + 64; W.tbase = u + 128; W.nk = u + 192; W.res = u + 256; W.tw = u + 320; W.mm = u + 384;
+      epv_seg_search_wave(S, s_rates, W, segs, outs, f_nseg, 0u, 64u, seed_lo, seed_hi, sweep, nielsen);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      P2_MARK(7);
+      for (uint32_t i = (uint32_t)lane; i < f_nbt; i += 64u)
+        epv_seg_assemble_one(S, s_rates, segs, outs, F.bt[f_wave * F.bt_cap + i], F.bfirst[f_wave * F.bt_cap + i], s0,
+                             seed_lo, seed_hi, sweep, nielsen);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      P2_MARK(8);
+    }
+    bool accepted = false, overflowed = false;
+    if (f_listed) {
+      AccLds A;
+      A.d = pool + lane; A.stride = 64u;
+      A.j = reinterpret_cast<uint32_t *>(pool + 512) + lane;
+      epv_meta_t *mc = reinterpret_cast<epv_meta_t *>(pool + 768) + lane;
+      const uint32_t r = epv_accept_site(S, s_const, s_blen, mc, 64u, F.meta_cache, A, seed_lo, seed_hi, sweep, tid, site,
+                                         own_first, own_last);
+      accepted = r & 1u; overflowed = (r & 2u) != 0u;
+    }
+    P2_MARK(9);
+    const unsigned long long am = __ballot(accepted), om = __ballot(overflowed);
+    if (lane == 0) {
+      if (am) atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_ACCEPT, my_shard)], (unsigned long long)__popcll(am));
+      if (om) atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_OVERFLOW, my_shard)], (unsigned long long)__popcll(om));
+      if (f_nbt) atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_COOP, my_shard)], (unsigned long long)f_nbt);
+    }
+  }
 #ifdef EPV_P2_PROFILE
   if (epv_lane() == 0) {
-    unsigned long long *row = epv_p2_prof + 8u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % EPV_P2_PROF_ROWS);
-    for (int q = 0; q < 7; ++q) row[q] += t_acc_[q];
-    row[7] += 1ull;
+    unsigned long long *row = epv_p2_prof + 16u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % EPV_P2_PROF_ROWS);
+    for (int q = 0; q < 15; ++q) row[q] += t_acc_[q];
+    row[15] += 1ull;
   }
 #endif
 }

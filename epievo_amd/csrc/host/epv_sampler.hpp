@@ -131,7 +131,7 @@ private:
   void free_stat_buffers();
   epv_ctx *ctx_;              // the context of the unsharded paths (== parts_[0].ctx when sharded)
   std::vector<int> devices_;
-  int contexts_wanted_ = 2;
+  int contexts_wanted_ = 3;
   uint32_t row_blocks_ = 64;  // 256-site blocks per row of the cross-GPU statistics stage
   bool force_comm_ = false;   // EPV_FORCE_COMM=1: the exchange layer even for one slot (tests)
   std::vector<Part> parts_;

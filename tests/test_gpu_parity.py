@@ -246,12 +246,20 @@ def test_long_branch_beyond_127_jumps(T, n):
     assert g.capacity() > maxj and g.capacity_events
 
 
-@pytest.mark.parametrize("cfg,n,env", [("tree", 20011, {"EPV_SEG_JUMPS": "1"}), ("pair", 9000, {"EPV_SEG_JUMPS": "0"}),
-                                       ("pair", 9000, {"EPV_SEG_JUMPS": "1"}), ("cat6", 3000, {"EPV_SEG_JUMPS": "1"}),
-                                       ("tree", 20011, {"EPV_PROPOSE_V1": "1"}), ("pair", 9000, {"EPV_PROPOSE_V1": "1"}),
-                                       ("bal16", 2000, {"EPV_PROPOSE_V2_GLOBAL": "1", "EPV_FORCE_GLOBAL_POOL": "1"}),
-                                       ("tree", 5000, {"EPV_FORCE_GLOBAL_POOL": "1", "EPV_PROPOSE_V2_GLOBAL": "1",
-                                                       "EPV_SEG_JUMPS": "1"})])
+_SEPARATE = {"EPV_FUSED_PHASE": "0"}      # small launches take the fused phase kernel by default
+@pytest.mark.parametrize("cfg,n,env", [("tree", 20011, dict(_SEPARATE, EPV_SEG_JUMPS="1")),
+                                       ("tree", 20011, dict(_SEPARATE, EPV_SEG_JUMPS="0")),
+                                       ("pair", 9000, dict(_SEPARATE, EPV_SEG_JUMPS="0")),
+                                       ("pair", 9000, dict(_SEPARATE, EPV_SEG_JUMPS="1")),
+                                       ("cat6", 3000, dict(_SEPARATE, EPV_SEG_JUMPS="1")),
+                                       ("tree", 20011, dict(_SEPARATE, EPV_PROPOSE_V1="1")),
+                                       ("pair", 9000, dict(_SEPARATE, EPV_PROPOSE_V1="1")),
+                                       ("bal16", 2000, dict(_SEPARATE, EPV_PROPOSE_V2_GLOBAL="1", EPV_FORCE_GLOBAL_POOL="1")),
+                                       ("tree", 5000, dict(_SEPARATE, EPV_FORCE_GLOBAL_POOL="1", EPV_PROPOSE_V2_GLOBAL="1",
+                                                           EPV_SEG_JUMPS="1")),
+                                       ("tree", 20011, {"EPV_FUSED_PHASE": "1"}), ("pair", 9000, {"EPV_FUSED_PHASE": "1"}),
+                                       ("cat6", 3000, {"EPV_FUSED_PHASE": "1"}),
+                                       ("tree", 20011, {"EPV_FUSED_PHASE": "1", "EPV_ACCEPT_NO_CACHE": "1"})])
 def test_every_kernel_path_is_bit_exact(cfg, n, env):
     """the library picks its kernels by workload (proposal kernel generation, where its record
     pool lives, sequential or segment-parallel jump sampling); every combination must give the
