@@ -225,8 +225,8 @@ int plan_p2(epv_ctx *c) {
   const uint64_t max_fit = fixed + 64u < 160u * 1024u ? (160u * 1024u - fixed) / 8u : 0u;
   uint64_t want = std::max(worst_dbl, typical_dbl);
   // the fused phase reuses the pool for the search's cooperative area and then for the accept
-  // stage's accumulators (768 doubles) and meta cache (5 B columns of 64 words)
-  if (fused) want = std::max<uint64_t>(want, std::max<uint64_t>(EPV_COOP_BYTES / 8u, 768u + 80u * (uint64_t)B));
+  // stage's task table, results, accumulators (992 doubles) and meta words (3 B columns of 64)
+  if (fused) want = std::max<uint64_t>(want, std::max<uint64_t>(EPV_COOP_BYTES / 8u, 992u + 48u * (uint64_t)B));
   const bool lds_ok = want <= max_fit && (fixed + want * 8u) * 5u <= 160u * 1024u;   // >= 5 waves per CU
   const bool use_lds = std::getenv("EPV_FORCE_GLOBAL_POOL") ? false
                        : std::getenv("EPV_FORCE_LDS_POOL") ? want <= max_fit : lds_ok;

@@ -563,15 +563,84 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       __builtin_amdgcn_wave_barrier();
       P2_MARK(8);
     }
+    // ---- acceptance.  A site's ratio needs the three triples around it (log_accept_rate,
+    //      SingleSiteSampler.cpp:409-429); they are independent, so every (listed site, triple)
+    //      pair gets its own lane -- a third of the chain, and on a short tree the lanes whose
+    //      proposal equalled their path would idle anyway.  pool: own[64] | res[192] | D[8][64] |
+    //      J[8][64] | meta words [3][B][64]
     bool accepted = false, overflowed = false;
-    if (f_listed) {
+    {
+      uint32_t *s_own = reinterpret_cast<uint32_t *>(pool);
+      double *s_res = pool + 32;
       AccLds A;
-      A.d = pool + lane; A.stride = 64u;
-      A.j = reinterpret_cast<uint32_t *>(pool + 512) + lane;
-      epv_meta_t *mc = reinterpret_cast<epv_meta_t *>(pool + 768) + lane;
-      const uint32_t r = epv_accept_site(S, s_const, s_blen, mc, 64u, F.meta_cache, A, seed_lo, seed_hi, sweep, tid, site,
-                                         own_first, own_last);
-      accepted = r & 1u; overflowed = (r & 2u) != 0u;
+      A.d = pool + 224 + lane; A.stride = 64u;
+      A.j = reinterpret_cast<uint32_t *>(pool + 736) + lane;
+      epv_meta_t *mc = reinterpret_cast<epv_meta_t *>(pool + 992) + lane;
+      const unsigned long long lmask = __ballot(f_listed);
+      const uint32_t n_listed = (uint32_t)__popcll(lmask);
+      const uint32_t my_rank = (uint32_t)__popcll(lmask & ((1ull << lane) - 1ull));
+      if (f_listed) s_own[my_rank] = (uint32_t)lane;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t site_lane0 = site - 3u * (uint64_t)lane, tid_lane0 = tid - (uint64_t)lane;
+      for (uint32_t t = (uint32_t)lane; t < 3u * n_listed; t += 64u) {
+        const uint32_t r = t / 3u, w = t - 3u * r, o = s_own[r];
+        const uint64_t osite = site_lane0 + 3u * (uint64_t)o, otid = tid_lane0 + o;
+        const uint64_t g = S.g0 + osite;
+        const bool skip = (S.prop_flag[otid] != 0) || (w == 0u && !(g > 1u)) || (w == 2u && !(g < S.n_global - 2u));
+        double v = 0.0;
+        if (!skip) {
+          const uint64_t c = osite - 1u + (uint64_t)w;            // centre column of this triple
+          // buffers of the three columns; the proposal (other buffer) stands in for the owner's site
+          uint32_t bl = S.sel[c - 1u], bm = S.sel[c], br = S.sel[c + 1u];
+          if (w == 0u) br ^= 1u; else if (w == 1u) bm ^= 1u; else bl ^= 1u;
+          if (F.meta_cache) {
+            const uint32_t B2 = S.B;
+#pragma unroll 4
+            for (uint32_t b = 0; b < B2; ++b) {
+              const epv_meta_t m0 = S.meta[meta_idx(S, bl, b, c - 1u)];
+              const epv_meta_t m1 = S.meta[meta_idx(S, bm, b, c)];
+              const epv_meta_t m2 = S.meta[meta_idx(S, br, b, c + 1u)];
+              mc[(0u * B2 + b) * 64u] = m0;
+              mc[(1u * B2 + b) * 64u] = m1;
+              mc[(2u * B2 + b) * 64u] = m2;
+            }
+            v = triple_llh_cached(S, s_const, s_blen, mc, 64u, 0u, bl, c - 1u, 1u, bm, c, 2u, br, c + 1u, A);
+          } else {
+            v = triple_llh(S, s_const, s_blen, bl, c - 1u, bm, c, br, c + 1u, A);
+          }
+        }
+        s_res[t] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (f_listed) {
+        // the owner: Metropolis_Hastings_site :510-533 with the three values (the arithmetic of
+        // epv_accept_site, term by term)
+        const uint32_t selM = S.sel[site];
+        const uint32_t gsite2 = (uint32_t)(S.g0 + site);
+        const bool ovf = S.prop_flag[tid] != 0;
+        double llh_l = S.tri[site - 1], llh_m = S.tri[site], llh_r = S.tri[site + 1];
+        double llr = (S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO) ? S.prop_llr[tid] : 0.0;
+        const double llh_l_orig = llh_l, llh_r_orig = llh_r;
+        if (!ovf) {
+          const uint64_t g = S.g0 + site;
+          if (g > 1u) llh_l = s_res[3u * my_rank];
+          llh_m = s_res[3u * my_rank + 1u];
+          if (g < S.n_global - 2u) llh_r = s_res[3u * my_rank + 2u];
+        }
+        llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
+        const double u = epv_keyed_block(seed_lo, seed_hi, gsite2, sweep, 0u, 0u, 0u, 0u).d0;
+        bool acc = (llr >= 0.0) || (u < epv_exp(llr));
+        if (ovf) { acc = false; overflowed = true; }
+        if (acc) {
+          S.sel[site] = (uint8_t)(selM ^ 1u);
+          S.tri[site - 1] = llh_l;
+          S.tri[site] = llh_m;
+          S.tri[site + 1] = llh_r;
+          accepted = site >= own_first && site <= own_last;
+        }
+      }
     }
     P2_MARK(9);
     const unsigned long long am = __ballot(accepted), om = __ballot(overflowed);
