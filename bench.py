@@ -282,6 +282,11 @@ def main():
             except Exception:
                 issue = None
         achieved_device = achieved * k_eff
+        from epievo_amd.sampler import DeviceSampler
+        phase_mode = ss.dev.phase_mode()
+        phase_kernels = DeviceSampler.PHASE_KERNELS[phase_mode]
+        if issue is not None:
+            issue["profiled_phase_mode"] = q.get("phase_mode")
         out = {
             "metric": "site-branch path resamples/sec at n=1e6, 4-leaf tree",
             "value": value, "unit": "site-branch resamples/s", "n_gpus": world,
@@ -299,13 +304,13 @@ def main():
                                    "%d GPU shard(s) x %d concurrent context(s) per GPU" % (ss.halo, world, k_eff)},
             # frac = what the DEVICE sustains: k_eff launches (one per context of this GPU) run
             # concurrently, each timed with its own HIP events on its own stream
-            "roofline": {"bound": "hbm", "kernel": "epv_mh_propose2_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel (one colour phase = one timed launch triple; large trees: epv_mh_propose_kernel)",
+            "roofline": {"bound": "hbm", "kernel": phase_kernels + " (one colour phase of one context = one timed launch group)",
                          "achieved": achieved_device,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_device / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_resample": bytes_per,
                          "resamples_per_launch": per_launch_units, "avg_launch_ms": avg_ms,
                          "launches_timed": n_launch, "concurrent_launches": k_eff,
-                         "achieved_per_launch": achieved, "issue": issue},
+                         "achieved_per_launch": achieved, "phase_mode": phase_mode, "issue": issue},
         }
         out["config"]["proposal_ratio"] = ("exact (q(old)/q(new) = 1 when the root state is kept: "
                                            "DESIGN.md section 4.1); same paths as the reference's sums")

@@ -717,6 +717,15 @@ EPV_API int epv_get_options(epv_ctx *c, uint32_t *flags) {
   return EPV_OK;
 }
 
+EPV_API int epv_phase_mode(epv_ctx *c, uint32_t *mode) {
+  if (!c || !mode || !c->have_paths) return EPV_ERR_ARG;
+  const bool refq = c->S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO;
+  static const bool p2_global = std::getenv("EPV_PROPOSE_V2_GLOBAL") != nullptr;
+  const bool p2 = c->use_p2 && !refq && (!c->p2_gpool || p2_global);
+  *mode = !p2 ? EPV_PHASE_V1 : c->fused ? EPV_PHASE_FUSED : seg_jumps_on(c) ? EPV_PHASE_V2_SEGMENTS : EPV_PHASE_V2;
+  return EPV_OK;
+}
+
 EPV_API int epv_get_capacity(epv_ctx *c, uint32_t *capacity) {
   if (!c || !capacity || !c->have_paths) return EPV_ERR_ARG;
   *capacity = c->S.C;

@@ -580,6 +580,10 @@ class LocalGroup:
         for s in self.subs:
             s.set_options(**kw)
 
+    def phase_mode(self):
+        """kernels of a colour phase (DeviceSampler.phase_mode) -- of the largest shard"""
+        return min(s.phase_mode() for s in self.subs)
+
     def kernel_time_ms(self):
         """launch-weighted mean duration of the shards' colour-phase launches, and their number"""
         tot, n = 0.0, 0

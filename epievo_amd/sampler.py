@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "epv_get_columns", "epv_put_columns", "epv_copy_columns", "epv_dev_alloc", "epv_dev_free",
     "epv_run_mcmc_blocks", "epv_reduce_blocks", "epv_get_counters", "epv_kernel_time_ms",
     "epv_set_timing", "epv_pack_columns_dev", "epv_unpack_columns_dev", "epv_device_of",
-    "epv_blocks_to_rows", "epv_reduce_rows", "epv_reduce_gathered_rows", "epv_dev_write", "epv_dev_read", "epv_set_options", "epv_get_options",
+    "epv_blocks_to_rows", "epv_reduce_rows", "epv_reduce_gathered_rows", "epv_dev_write", "epv_dev_read", "epv_set_options", "epv_get_options", "epv_phase_mode",
 ]
 
 
@@ -109,6 +109,7 @@ def lib():
                                                dp, dp]
         L.epv_set_options.argtypes = [vp, C.c_uint32]
         L.epv_get_options.argtypes = [vp, C.POINTER(C.c_uint32)]
+        L.epv_phase_mode.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.epv_dev_write.argtypes = [vp, vp, vp, C.c_uint64]
         L.epv_dev_read.argtypes = [vp, vp, vp, C.c_uint64]
         L.epv_get_counters.argtypes = [vp, C.POINTER(_Counters)]
@@ -192,6 +193,19 @@ class DeviceSampler:
         """see EPV_OPT_* in include/epievo_mi355x.h"""
         self._ck(self.L.epv_set_options(self.h, (1 if reference_proposal_ratio else 0) |
                                         (2 if forward_rejection else 0)))
+
+    PHASE_KERNELS = {
+        0: "epv_mh_propose_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel",
+        1: "epv_mh_propose2_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel",
+        2: "epv_mh_propose2_kernel + epv_seg_search_kernel + epv_seg_assemble_kernel + epv_mh_accept_kernel",
+        3: "epv_mh_propose2_kernel<fused>: proposal, segment search, assembly and acceptance in one launch",
+    }
+
+    def phase_mode(self):
+        """EPV_PHASE_* of include/epievo_mi355x.h: which kernels a colour phase launches"""
+        v = C.c_uint32(0)
+        self._ck(self.L.epv_phase_mode(self.h, C.byref(v)))
+        return int(v.value)
 
     def capacity(self):
         v = C.c_uint32(0)

@@ -106,6 +106,15 @@ int epv_set_capacity(epv_ctx *ctx, uint32_t capacity);
 int epv_get_capacity(epv_ctx *ctx, uint32_t *capacity);
 int epv_set_options(epv_ctx *ctx, uint32_t flags);
 int epv_get_options(epv_ctx *ctx, uint32_t *flags);
+/* Which kernels a colour phase of the resident paths launches (chosen by tree size, mean jumps per
+ * branch and launch size; results are bit-identical in every mode) -- for profiles and bench lines:
+ * 0 = epv_mh_propose_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel (large trees, reference
+ *     proposal arithmetic), 1 = epv_mh_propose2_kernel + jumps + accept, 2 = epv_mh_propose2_kernel +
+ *     epv_seg_search_kernel + epv_seg_assemble_kernel + accept (long branches), 3 = the fused phase:
+ *     one epv_mh_propose2_kernel launch that also samples the jump times and accepts (launches of few
+ *     waves).  No reference counterpart. */
+enum { EPV_PHASE_V1 = 0, EPV_PHASE_V2 = 1, EPV_PHASE_V2_SEGMENTS = 2, EPV_PHASE_FUSED = 3 };
+int epv_phase_mode(epv_ctx *ctx, uint32_t *mode);
 
 /* initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device, for the
  * two-node tree of one branch (epv_set_tree with n_nodes = 2 and epv_set_model first):

@@ -67,7 +67,11 @@ def main():
                 tc += mean["SQ_THREAD_CYCLES_VALU"]
     ij = os.path.join(here, "issue.json")
     data = json.load(open(ij)) if os.path.exists(ij) else {}
-    data[config] = {"round": tag, "kernels": "+".join(k for k in sorted(acc) if k in MH),
+    mh = [k for k in sorted(acc) if k in MH]
+    # EPV_PHASE_* of include/epievo_mi355x.h, from the kernels that ran
+    mode = 3 if mh == ["epv_mh_propose2_kernel"] else 0 if "epv_mh_propose_kernel" in mh else \
+        2 if "epv_seg_search_kernel" in acc else 1
+    data[config] = {"round": tag, "kernels": "+".join(mh), "phase_mode": mode,
                     "valu_wave_insts_per_launch": total, "cycles_per_inst": 4, "simds": SIMDS,
                     "clock_ghz": CLOCK_GHZ, "resamples_per_launch": units,
                     "lane_utilisation": tc / total / 64.0 if total else None}

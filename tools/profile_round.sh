@@ -14,7 +14,10 @@ cat $out/bench.json
 rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-reference-leg > $out/bench_traced.json 2> $out/trace.err || exit 1
 python tools/kstats.py $(find $out/trace -name "*kernel_trace.csv" -o -name "*results.db" | head -1) > $out/kstats.txt
 cat $out/kstats.txt
-# counters: one context per GPU so that every launch covers a whole colour phase
+# counters: one context per GPU so that every launch covers a whole colour phase, in the phase mode
+# the bench line above ran in (three contexts of 1736 waves each take the fused kernel; one context
+# of 5209 waves would not by itself)
+export EPV_FUSED_PHASE=$(python -c "import json; print(1 if json.load(open('$out/bench.json'))['roofline'].get('phase_mode') == 3 else 0)")
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES -d $out/pmc_sq -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-reference-leg --shards-per-gpu 1 > $out/pmc_sq.json 2> $out/pmc_sq.err || exit 1
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-reference-leg --shards-per-gpu 1 > /dev/null 2> $out/pmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-reference-leg --shards-per-gpu 1 > /dev/null 2> $out/pmc_write.err || exit 1
