@@ -127,9 +127,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-leg", action="store_true",
                     help="skip the extra steps in reference-arithmetic mode (profiling runs)")
-    ap.add_argument("--shards-per-gpu", type=int, default=3,
-                    help="contexts per GPU (epievo_amd.parallel.LocalGroup): their dependent kernels "
-                         "overlap; results are bit-identical to 1")
+    ap.add_argument("--shards-per-gpu", type=int, default=0,
+                    help="contexts per GPU (epievo_amd.parallel.LocalGroup): their launches fill each "
+                         "other's tails; results are bit-identical to 1.  0 = by tree size: 3 on small "
+                         "trees (fused colour phase), 2 on large ones")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) is the product path; gloo lets several ranks share one "
                          "GPU to rehearse the N>1 code path on a 1-GPU box")
@@ -186,7 +187,7 @@ def main():
     fp_own = host.simulate(model, tree, n_own, SEED + rank)
     kbar = len(fp_own.jumps) / float(n_own * (tree.n_nodes - 1))
 
-    k_local = max(1, args.shards_per_gpu)
+    k_local = args.shards_per_gpu if args.shards_per_gpu > 0 else (3 if tree.n_nodes - 1 <= 8 else 2)
     ss = ShardedSampler(comm, device=local_rank,
                         device_factory=(lambda dev: LocalGroup(dev, k_local, BURN_IN + BATCH)) if k_local > 1 else None)
     # 16 jump slots per (site, branch) on the short trees; the T = 1 branch picks its own

@@ -69,7 +69,7 @@ struct epv_ctx {
                                  // (long branches, kbar >= 0.25), EPV_SEG_JUMPS=0/1 forces
   // fused colour phase (epv_propose2.h, FUSED): one kernel per phase for launches of few waves
   int use_fused = -1;            // -1 = by launch size (EPV_FUSED_MAX_WAVES), EPV_FUSED_PHASE=0/1 forces
-  uint32_t fused_max_waves = 4096;   // measured on tree.nwk: +46 % at 520 waves, +5 % at 2600, -4 % at 5200 (tools/fused_scan.sh)
+  uint32_t fused_max_waves = 3072;   // measured on tree.nwk: +46 % at 520 waves, +20 % at 1700, +5 % at 2600, -4..-14 % at 5200 (tools/fused_scan.sh)
   bool fused = false;            // decided by plan_p2 for the uploaded paths
   uint32_t fused_lanes = 64;     // sites per wave of the fused phase (64 / 32 / 16: EPV_FUSED_LANES, else by launch size)
   EpvFused F{};                  // per-wave lists, allocated on first use

@@ -149,7 +149,7 @@ bool SingleSiteSampler::uses_rccl() const {
 std::string SingleSiteSampler::layout() const {
   std::ostringstream o;
   if (!sharded()) { o << "1 context on device " << devices_[0]; return o.str(); }
-  o << slots_.size() << " GPU slot(s) x up to " << contexts_wanted_ << " context(s) = " << parts_.size()
+  o << slots_.size() << " GPU slot(s) x up to " << contexts_per_gpu() << " context(s) = " << parts_.size()
     << " parts, halo " << halo_ << " columns";
   if (slots_[0].comm)
     o << ", statistics rows of " << kBlock * row_blocks_ << " sites, exchange over "
@@ -264,7 +264,7 @@ void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &p
   std::vector<Piece> pieces;
   for (size_t g = 0; g < G; ++g) {
     const uint64_t len = cut[g + 1] - cut[g];
-    size_t k = (size_t)contexts_wanted_;
+    size_t k = (size_t)contexts_per_gpu();
     while (k > 1 && len < k * min_part) --k;
     for (size_t j = 0; j < k; ++j) {
       const uint64_t a = j == 0 ? cut[g] : cut[g] + round_to((double)j * (double)len / (double)k, kBlock);

@@ -100,6 +100,7 @@ public:
   size_t n_slots() const { return slots_.size(); }
   bool uses_rccl() const;
   std::string layout() const;
+  int contexts_per_gpu() const { return contexts_wanted_ > 0 ? contexts_wanted_ : (n_nodes_ - 1 <= 8 ? 3 : 2); }
 
 private:
   struct Part {            // one context: local columns [lo, hi), owned columns [a, b) of the genome
@@ -131,7 +132,7 @@ private:
   void free_stat_buffers();
   epv_ctx *ctx_;              // the context of the unsharded paths (== parts_[0].ctx when sharded)
   std::vector<int> devices_;
-  int contexts_wanted_ = 3;
+  int contexts_wanted_ = 0;      // contexts per GPU; 0 = by tree size (3 up to 8 branches: fused colour phase; else 2)
   uint32_t row_blocks_ = 64;  // 256-site blocks per row of the cross-GPU statistics stage
   bool force_comm_ = false;   // EPV_FORCE_COMM=1: the exchange layer even for one slot (tests)
   std::vector<Part> parts_;

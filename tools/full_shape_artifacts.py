@@ -6,7 +6,7 @@ profiles/ (run on the GPU box through gpurun; results land in gpurun_out/<tag>/ 
     <tag>_bench_config4_genome_n1e7.json    bench.py --sites 10000000  (config 4's genome on one GPU)
     <tag>_bench_config5_shard_bal16.json    bench.py --config bal16 --sites 1250000 (one GPU's share)
     <tag>_config3_cli_e2e.txt               config 3 through the drop-in CLI, file IO included;
-                                            one context, the default two, and four rehearsal slots
+                                            one context, the default three, and four rehearsal slots
 """
 import json, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +40,7 @@ open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
 model, tree, fp = simulate("tree", 1000000, seed=42)
 host.write_paths(d + "/in.paths", tree.node_names, tree.branches, fp)
 lines = []
-for name, env in (("one context", {"EPV_CONTEXTS_PER_GPU": "1"}), ("two contexts (default)", {}),
+for name, env in (("one context", {"EPV_CONTEXTS_PER_GPU": "1"}), ("three contexts (default)", {}),
                   ("four rehearsal slots on one GPU", {"EPV_DEVICES": "0,0,0,0", "EPV_CONTEXTS_PER_GPU": "1"})):
     t0 = time.time()
     r = subprocess.run([_build.BIN_DIR + "/epievo_est_params_histories", "-i", "20", "-B", "50", "-L", "10", "-s", "42",
