@@ -79,7 +79,9 @@ struct epv_ctx {
   size_t mh_lds = 0;
   // counters / timing
   uint64_t n_sweeps = 0, tot_overflow = 0, tot_coop = 0;
-  bool timing = false;
+  bool timing = false;           // events around THIS launch (set per launch from timing_every)
+  uint32_t timing_every = 0;     // 0 = off, N = HIP events around every N-th colour-phase launch
+  uint64_t timing_seen = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double timed_ms = 0.0;
@@ -371,6 +373,7 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   const uint64_t blocks = (threads + c->mh_threads - 1u) / c->mh_threads;
   if (blocks == 0) return EPV_OK;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  c->timing = c->timing_every && (c->timing_seen++ % c->timing_every) == 0u;
   if (c->timing) {
     if (c->ev_used == c->ev_pool.size()) {
       hipEvent_t a, b;
@@ -1535,7 +1538,9 @@ EPV_API int epv_debug_p2_profile(unsigned long long *out) {
 
 EPV_API int epv_set_timing(epv_ctx *c, int enabled) {
   if (!c) return EPV_ERR_ARG;
-  c->timing = enabled != 0;
+  c->timing_every = enabled > 0 ? (uint32_t)enabled : 0u;
+  c->timing_seen = 0;
+  c->timing = false;
   return EPV_OK;
 }
 

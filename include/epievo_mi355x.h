@@ -264,7 +264,8 @@ int epv_get_counters(epv_ctx *ctx, epv_counters *out);
 
 /* Timing hook for bench.py: average duration (ms) of the colour-phase kernel launches
  * issued since the last call, measured with HIP events on the context's stream, and
- * how many launches that covers. */
+ * how many launches that covers.  epv_set_timing(ctx, N): 0 = off, N >= 1 = events around every
+ * N-th colour-phase launch (every launch costs ~4 % of a step at three contexts per GPU). */
 int epv_kernel_time_ms(epv_ctx *ctx, double *avg_ms, uint64_t *n_launches);
 int epv_set_timing(epv_ctx *ctx, int enabled);
 
