@@ -298,3 +298,28 @@ print("ok")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), cfg, n)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_phase_mode_follows_the_workload():
+    """epv_phase_mode (include/epievo_mi355x.h): small launches take the fused colour phase, the
+    reference's proposal arithmetic and large trees the first proposal kernel, a large capacity
+    (more than 64 segments per branch possible) the separate kernels; the choice never changes a
+    number (test_every_kernel_path_is_bit_exact forces each against rung B)"""
+    from common import simulate
+    from epievo_amd.sampler import DeviceSampler
+    model, tree, fp = simulate("tree", 20011, seed=6)
+    d = DeviceSampler(0); d.set_tree(tree); d.set_model(model); d.upload_paths(fp, 16); d.reset()
+    assert d.phase_mode() == 3
+    J0, D0, n0 = d.run_mcmc(1, 2, 5)
+    d.set_options(reference_proposal_ratio=True)
+    assert d.phase_mode() == 0
+    d.set_options()
+    d.set_capacity(40)                      # 2 C + 1 > 64: the fused phase's hand-over word is too short
+    assert d.phase_mode() in (1, 2)
+    d.reset()
+    d2 = DeviceSampler(0); d2.set_tree(tree); d2.set_model(model); d2.upload_paths(fp, 40); d2.reset()
+    J1, D1, n1 = d2.run_mcmc(1, 2, 5)
+    assert n1 == n0 and np.array_equal(J1, J0) and np.array_equal(D1, D0)
+    model, tree, fp = simulate("bal16", 2000, seed=6)
+    d3 = DeviceSampler(0); d3.set_tree(tree); d3.set_model(model); d3.upload_paths(fp, 16); d3.reset()
+    assert d3.phase_mode() == 0             # record pool in global memory: first proposal kernel
