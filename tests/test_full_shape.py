@@ -128,3 +128,29 @@ def test_config5_shard_through_the_cli(tmp_path):
         assert jb.size == 0 or (jb.min() > 0 and jb.max() < tt[b])
         assert abs(t2.branches[b] - tt[b]) < 1e-5 * tt[b]
     assert np.all(np.isfinite(host.Model.read(d + "/one.param", scale=True).rates))
+
+
+def test_config3_fused_contexts_equal_one_context_of_separate_kernels():
+    """the bench's own configuration (tree.nwk, n = 1e6, -L 10 -B 50): three contexts, each small
+    enough for the fused colour phase, against ONE context, whose 5209-wave phases take the separate
+    proposal / jump / accept kernels -- every number the same, bit for bit"""
+    from epievo_amd.parallel import LocalGroup
+    from epievo_amd.sampler import DeviceSampler
+    n, burn, batch, seed = 1_000_000, 10, 50, 42
+    model, tree, fp = simulate("tree", n, seed=42)
+    d = DeviceSampler(0)
+    d.set_tree(tree); d.set_model(model); d.upload_paths(fp, 16)
+    assert d.phase_mode() == 1
+    d.reset()
+    J, D, nacc = d.run_mcmc(burn, batch, seed)
+    tri, p = d.tri_llh(), d.paths()
+    d.close()
+    g = LocalGroup(0, 3, burn + batch)
+    g.set_tree(tree); g.set_model(model); g.upload_paths(fp, 16)
+    assert len(g.subs) == 3 and g.phase_mode() == 3
+    g.reset()
+    Jg, Dg, ng = g.run_mcmc(burn, batch, seed)
+    assert ng == nacc and np.array_equal(Jg, J) and np.array_equal(Dg, D)
+    assert np.array_equal(g.tri_llh(), tri)
+    assert orc.paths_equal(g.paths(), p)
+    g.close()
