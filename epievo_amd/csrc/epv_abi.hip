@@ -409,6 +409,8 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     EpvFused F = c->F;
     F.meta_cache = meta_cache;
     F.lanes = c->fused_lanes;
+    static const int grouped = std::getenv("EPV_FUSED_GROUPED_ROUNDS") ? std::atoi(std::getenv("EPV_FUSED_GROUPED_ROUNDS")) : 4;
+    F.grouped_rounds = (uint32_t)std::max(0, grouped);
     hipLaunchKernelGGL((epv_mh_propose2_kernel<false, true, true>), dim3(pb), dim3(pt), c->p2_lds, c->stream, c->S,
                        (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi,
                        c->p2_pool, c->p2_list_cap, 0u, c->d_counters, (double *)nullptr, c->d_segtab, F);

@@ -159,6 +159,62 @@ __global__ __launch_bounds__(256, EPV_SEARCH_WAVES) void epv_seg_search_kernel(E
                       seed_hi, sweep, nielsen);
 }
 
+// A SHORT list (n_seg <= 32, one wave): G = 64 / n_seg lanes per segment, lane `sub` of a group
+// evaluating trials 1 + sub, 1 + sub + G, ... -- one trial per lane and round instead of a lane
+// walking its segment's trials alone while most of the wave idles (a 64-site wave of tree.nwk
+// lists ~20 dirty segments).  The lowest non-failing trial wins and M is the most jumps of any
+// trial up to it, whoever evaluated them, so the results are those of epv_seg_search_wave.
+// Returns false when some segment is still open after `rounds` rounds (long tails belong to the
+// wave-wide cooperative search): the caller then runs epv_seg_search_wave over the whole list.
+__device__ __forceinline__ bool epv_seg_search_grouped(const EpvDev &S, const double *s_rates, const EpvSegTask *segs,
+                                                       EpvSegOut *outs, uint32_t n_seg, uint32_t G, uint32_t rounds,
+                                                       uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, bool nielsen) {
+  const int lane = epv_lane();
+  const uint32_t seg = (uint32_t)lane / G, sub = (uint32_t)lane - seg * G, gbase = seg * G;
+  EpvSegTask t;
+  t.w0 = 0ull; t.len = -1.0; t.start = 0.0; t.w3 = 0ull;
+  if (seg < n_seg) t = segs[seg];
+  const uint32_t gsite = (uint32_t)(S.g0 + (t.w0 & 0xffffffffffull));
+  const uint32_t node = (uint32_t)(t.w0 >> 40) & 4095u, k = (uint32_t)(t.w0 >> 52);
+  const uint32_t prev = (uint32_t)t.w3 & 1u, sampled = (uint32_t)(t.w3 >> 1) & 1u, trip0 = (uint32_t)(t.w3 >> 2) & 7u;
+  const double len = t.len, r0 = s_rates[trip0], r1 = s_rates[trip0 | 2u];
+  bool pend = seg < n_seg && t.len >= 0.0;
+  double trunc = 0.0;
+  if (pend && sampled != prev) trunc = 1.0 - epv_exp(-(prev ? r1 : r0) * len);
+  uint32_t tcur = 1u + sub, hist = 0u;      // hist: most jumps of this lane's failed trials so far
+  for (uint32_t r = 0; r < rounds && __any(pend); ++r) {
+    int oc = TRIAL_FAIL;
+    uint32_t cnt = 0u, tw = 0u, mm = 0u;
+    double jt[2] = {0.0, 0.0};
+    if (pend)
+      oc = scan_trials(seed_lo, seed_hi, gsite, sweep, node, k, tcur, 1u, prev, sampled, len, r0, r1, trunc, 0xffffffffu,
+                       jt, 1u, 2u, t.start, tw, cnt, nielsen, &mm);
+    const unsigned long long hit = __ballot(pend && oc != TRIAL_FAIL);
+    const uint32_t gh = (uint32_t)(hit >> gbase) & ((1u << G) - 1u);     // this group's hits (G <= 8)
+    const uint32_t wsub = gh ? (uint32_t)__ffs((int)gh) - 1u : G;         // the group's lowest hit
+    // jumps that count towards M: everybody's earlier (failed) trials, this round's trials up to the winner's
+    uint32_t m = (sub <= wsub && mm > hist) ? mm : hist;
+    uint32_t m_all = 0u;
+    for (uint32_t q = 0; q < G; ++q) {
+      const uint32_t v = __shfl(m, (int)((gbase + q) & 63u));
+      m_all = v > m_all ? v : m_all;
+    }
+    if (pend && gh) {
+      if (sub == wsub) {
+        EpvSegOut o;
+        o.cnt = cnt; o.tstar = tcur; o.maxm = m_all; o.pad = 0u;
+        o.j0 = jt[0]; o.j1 = jt[1];
+        outs[seg] = o;
+      }
+      pend = false;
+    } else {
+      hist = m;
+      tcur += G;
+    }
+  }
+  return !__any(pend);
+}
+
 // one dirty branch (task word bt, its segments at segs/outs[first ..]): results in order into the
 // proposal; a capacity overflow flags the site (phase index tid)
 __device__ __forceinline__ void epv_seg_assemble_one(const EpvDev &S, const double *s_rates, const EpvSegTask *segs,

@@ -138,6 +138,7 @@ struct EpvFused {
   uint32_t seg_cap, bt_cap;    // per wave: 64 B (2C+1) and 64 B -- the worst case, so nothing overflows
   uint32_t meta_cache;         // accept stage: meta words of the five columns in LDS (B <= 8)
   uint32_t lanes;              // sites per wave
+  uint32_t grouped_rounds;     // rounds of the grouped search of short segment lists (0 = off)
 };
 
 template <bool GPOOL, bool SEG, bool FUSED>
@@ -552,7 +553,14 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       W.len = pool; W.r0 = pool + 64; W.r1 = pool + 128; W.trunc = pool + 192; W.tj = pool + 256;
       uint32_t *u = reinterpret_cast<uint32_t *>(pool + 384);
       W.misc = u; W.gsite = u + 64; W.tbase = u + 128; W.nk = u + 192; W.res = u + 256; W.tw = u + 320; W.mm = u + 384;
-      epv_seg_search_wave(S, s_rates, W, segs, outs, f_nseg, 0u, 64u, seed_lo, seed_hi, sweep, nielsen);
+      // a short list: several lanes per segment first (epv_seg_search_grouped); the wave-wide search
+      // takes whatever is longer, and whatever a few rounds of that leave open
+      bool done = false;
+      if (f_nseg <= 32u && F.grouped_rounds) {
+        const uint32_t G = 64u / f_nseg > 8u ? 8u : 64u / f_nseg;
+        done = epv_seg_search_grouped(S, s_rates, segs, outs, f_nseg, G, F.grouped_rounds, seed_lo, seed_hi, sweep, nielsen);
+      }
+      if (!done) epv_seg_search_wave(S, s_rates, W, segs, outs, f_nseg, 0u, 64u, seed_lo, seed_hi, sweep, nielsen);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
       P2_MARK(7);
