@@ -227,7 +227,7 @@ __device__ __forceinline__ void epv_seg_assemble_one(const EpvDev &S, const doub
   const uint32_t b = (uint32_t)(bt >> 40) & 4095u, nds = (uint32_t)(bt >> 52) & 127u, end_state = (uint32_t)(bt >> 59) & 1u;
   const uint32_t selP = S.sel[site] ^ 1u;
   epv_meta_t *meta = S.meta + meta_idx(S, selP, b, site);
-  double *dst = S.jumps + ((uint64_t)selP * B + b) * C * n + site;
+  double *dst = S.jumps + jump_idx(S, selP, b, site);
   const uint32_t start_state = (uint32_t)(*meta >> EPV_INIT_SHIFT);
   uint32_t cnt = 0;
   bool ovf = false;

@@ -86,8 +86,16 @@ __device__ __forceinline__ double wave_tree_sum16(const double v[16], int lane, 
 
 // ------------------------------------------------------------------ path access
 // meta layout, see epv_device.h (branch-major by default)
+// (buf, b, site) -> element; buf is 0 or 1 and differs from lane to lane, so the buffer offset is a
+// select rather than a multiply (64-bit and 32-bit integer multiplies are quarter-rate on the
+// vector unit; b is wave-uniform at nearly every call site, where b * n stays on the scalar unit)
 __device__ __forceinline__ uint64_t meta_idx(const EpvDev &S, uint32_t buf, uint32_t b, uint64_t site) {
-  return ((uint64_t)buf * S.B + b) * S.n + site;
+  return (buf ? (uint64_t)S.B * S.n : 0ull) + (uint64_t)b * S.n + site;
+}
+// first jump slot of (buf, b, site) in S.jumps
+__device__ __forceinline__ uint64_t jump_idx(const EpvDev &S, uint32_t buf, uint32_t b, uint64_t site) {
+  const uint64_t Cn = (uint64_t)S.C * S.n;
+  return (buf ? (uint64_t)S.B * Cn : 0ull) + (uint64_t)b * Cn + site;
 }
 struct PathRef {
   const double *j;  // jump k lives at j[k * n]
@@ -96,10 +104,9 @@ struct PathRef {
 };
 __device__ __forceinline__ PathRef path_ref(const EpvDev &S, uint32_t buf, uint32_t b,
                                             uint64_t site) {
-  const uint64_t plane = (uint64_t)buf * S.B + b;
   const epv_meta_t m = S.meta[meta_idx(S, buf, b, site)];
   PathRef p;
-  p.j = S.jumps + plane * S.C * S.n + site;
+  p.j = S.jumps + jump_idx(S, buf, b, site);
   p.nj = m & EPV_NJ_MASK;
   p.init = m >> EPV_INIT_SHIFT;
   return p;
@@ -215,9 +222,9 @@ __device__ __forceinline__ double triple_llh_cached(const EpvDev &S, const doubl
   for (uint32_t b = 0; b < B; ++b) {
     const uint32_t ml = mc[(cl * B + b) * stride], mm = mc[(cm * B + b) * stride], mr = mc[(cr * B + b) * stride];
     PathRef L, M, R;
-    L.j = S.jumps + ((uint64_t)bl * B + b) * S.C * S.n + sl; L.nj = ml & EPV_NJ_MASK; L.init = ml >> EPV_INIT_SHIFT;
-    M.j = S.jumps + ((uint64_t)bm * B + b) * S.C * S.n + sm; M.nj = mm & EPV_NJ_MASK; M.init = mm >> EPV_INIT_SHIFT;
-    R.j = S.jumps + ((uint64_t)br * B + b) * S.C * S.n + sr; R.nj = mr & EPV_NJ_MASK; R.init = mr >> EPV_INIT_SHIFT;
+    L.j = S.jumps + jump_idx(S, bl, b, sl); L.nj = ml & EPV_NJ_MASK; L.init = ml >> EPV_INIT_SHIFT;
+    M.j = S.jumps + jump_idx(S, bm, b, sm); M.nj = mm & EPV_NJ_MASK; M.init = mm >> EPV_INIT_SHIFT;
+    R.j = S.jumps + jump_idx(S, br, b, sr); R.nj = mr & EPV_NJ_MASK; R.init = mr >> EPV_INIT_SHIFT;
     if (b == 0) { rl = L.init; rm = M.init; rr = R.init; }
     merge3(L, M, R, S.n, s_blen[b + 1], A);
   }

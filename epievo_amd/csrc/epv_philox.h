@@ -44,10 +44,20 @@ __device__ __forceinline__ epv_block2 epv_keyed_block(uint32_t seed_lo, uint32_t
   uint32_t k0 = seed_lo, k1 = seed_hi;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
+#if !defined(EPV_PHILOX_MUL_HI_LO)
+    // one v_mad_u64_u32 per 32 x 32 -> 64 product instead of the v_mul_hi_u32 + v_mul_lo_u32 the
+    // compiler picks (all three are quarter-rate on CDNA: 20 instead of 40 slow multiplies per
+    // block; +2..4 % end to end, tools/ab_bench.py; the same bits)
+    unsigned long long p0, p1;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p0) : "s"(EPV_PHILOX_M0), "v"(c0) : "vcc");
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "s"(EPV_PHILOX_M1), "v"(c2) : "vcc");
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
     const uint32_t hi0 = __umulhi(EPV_PHILOX_M0, c0);
     const uint32_t lo0 = EPV_PHILOX_M0 * c0;
     const uint32_t hi1 = __umulhi(EPV_PHILOX_M1, c2);
     const uint32_t lo1 = EPV_PHILOX_M1 * c2;
+#endif
     const uint32_t n0 = hi1 ^ c1 ^ k0;
     const uint32_t n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
