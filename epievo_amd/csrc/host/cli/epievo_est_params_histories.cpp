@@ -13,6 +13,7 @@
 #include <limits>
 #include <random>
 #include <stdexcept>
+#include <chrono>
 #include <thread>
 
 #include "epv_io.hpp"
@@ -129,7 +130,12 @@ int main(int argc, const char **argv) {
     vector<double> out_branches;
     epv::SingleSiteSampler mcmc(burnin, batch,
                                 gpu_list.empty() ? epv::devices_from_env() : epv::parse_device_list(gpu_list));
+    // EPV_CLI_TIMING=1: where the wall clock of the iterations went (stderr, at the end)
+    const bool timing = std::getenv("EPV_CLI_TIMING") != nullptr;
+    double t_reset = 0, t_mcmc = 0, t_mstep = 0, t_scale = 0, t_wait = 0, t_download = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t itr = 0; itr < iteration; itr++) {
+      double t0 = now();
       if (itr == 0) {
         mcmc.reset(the_model, th, paths);
         if (VERBOSE) cerr << "[GPU LAYOUT: " << mcmc.layout() << "]" << endl;
@@ -137,9 +143,11 @@ int main(int argc, const char **argv) {
         mcmc.reset(the_model);
       }
 
+      t_reset += now() - t0; t0 = now();
       double acceptance_rate;
       vector<vector<double>> J_accum, D_accum;
       mcmc.run_mcmc(rng_seed, itr, J_accum, D_accum, acceptance_rate);
+      t_mcmc += now() - t0; t0 = now();
 
       /* PARAMETER ESTIMATION (host) */
       const int B = th.n_nodes() - 1;
@@ -154,7 +162,9 @@ int main(int argc, const char **argv) {
         llh = epv::estimate_rates_and_branches(param_tol, th.n_nodes(), J.data(), D.data(), th.branches,
                                                the_model);
       }
+      t_mstep += now() - t0; t0 = now();
       mcmc.scale_jump_times(th.branches);
+      t_scale += now() - t0;
 
       if (VERBOSE)
         cerr << itr + 1 << "\t" << the_model.T[0] << "\t" << the_model.T[3] << "\t"
@@ -166,9 +176,12 @@ int main(int argc, const char **argv) {
         if (!out_param) throw std::runtime_error("bad output param file: " + param_file_updated);
         out_param << the_model.format_for_param_file() << endl;
       }
+      t0 = now();
       if (writer.joinable()) writer.join();
       if (!writer_error.empty()) throw std::runtime_error(writer_error);
+      t_wait += now() - t0; t0 = now();
       mcmc.download(out_paths);
+      t_download += now() - t0;
       out_branches = th.branches;
       writer = std::thread([&outfile, &th, &out_paths, &out_branches, &writer_error] {
         try {
@@ -182,8 +195,14 @@ int main(int argc, const char **argv) {
         out_tree << th.newick() << endl;
       }
     }
+    const double t0 = now();
     if (writer.joinable()) writer.join();
     if (!writer_error.empty()) throw std::runtime_error(writer_error);
+    t_wait += now() - t0;
+    if (timing)
+      cerr << "[TIMING over " << iteration << " iterations, seconds: reset " << t_reset << ", run_mcmc " << t_mcmc
+           << ", M-step " << t_mstep << ", scale_jump_times " << t_scale << ", waiting for the previous file "
+           << t_wait << ", download " << t_download << "]" << endl;
   } catch (const std::exception &e) {
     cerr << e.what() << endl;
     return EXIT_FAILURE;

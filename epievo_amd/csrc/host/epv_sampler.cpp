@@ -357,7 +357,16 @@ void SingleSiteSampler::reset(const Model &m) {
   }
   for (Part &p : parts_) check_on(p.ctx, epv_set_model(p.ctx, m.rates.data(), m.T.data()), "epv_set_model");
   refresh_parts();
-  for (Part &p : parts_) check_on(p.ctx, epv_reset(p.ctx), "epv_reset");
+  // the parts' cached likelihoods, each on its own stream from its own host thread
+  std::vector<std::string> errors(parts_.size());
+  std::vector<std::thread> workers;
+  for (size_t i = 0; i < parts_.size(); ++i)
+    workers.emplace_back([this, i, &errors] {
+      try { check_on(parts_[i].ctx, epv_reset(parts_[i].ctx), "epv_reset"); }
+      catch (const std::exception &e) { errors[i] = e.what(); }
+    });
+  for (std::thread &w : workers) w.join();
+  for (const std::string &e : errors) if (!e.empty()) throw std::runtime_error(e);
 }
 
 void SingleSiteSampler::ensure_stat_buffers() {
@@ -549,22 +558,31 @@ void SingleSiteSampler::indep_update_paths(const double rates[2], uint64_t seed,
 
 void SingleSiteSampler::download(FlatPaths &paths) {
   if (sharded()) {
-    std::vector<FlatPaths> owned;
-    for (Part &q : parts_) {
-      epv_ctx *c = q.ctx;
-      uint64_t total = 0;
-      check_on(c, epv_paths_total_jumps(c, &total), "epv_paths_total_jumps");
-      FlatPaths p;
-      p.n_sites = q.hi - q.lo;
-      p.n_nodes = n_nodes_;
-      const uint64_t E = (uint64_t)(n_nodes_ - 1) * p.n_sites;
-      p.init.assign(E, 0);
-      p.offsets.assign(E + 1, 0);
-      p.jumps.assign(total ? total : 1, 0.0);
-      check_on(c, epv_download_paths(c, p.init.data(), p.offsets.data(), p.jumps.data()), "epv_download_paths");
-      p.jumps.resize(total);
-      owned.push_back(slice_sites(p, q.a - q.lo, q.b - q.lo));
-    }
+    // every part on its own host thread (its context has its own stream): gather, copy, trim halos
+    std::vector<FlatPaths> owned(parts_.size());
+    std::vector<std::string> errors(parts_.size());
+    std::vector<std::thread> workers;
+    for (size_t i = 0; i < parts_.size(); ++i)
+      workers.emplace_back([this, i, &owned, &errors] {
+        try {
+          Part &q = parts_[i];
+          epv_ctx *c = q.ctx;
+          uint64_t total = 0;
+          check_on(c, epv_paths_total_jumps(c, &total), "epv_paths_total_jumps");
+          FlatPaths p;
+          p.n_sites = q.hi - q.lo;
+          p.n_nodes = n_nodes_;
+          const uint64_t E = (uint64_t)(n_nodes_ - 1) * p.n_sites;
+          p.init.assign(E, 0);
+          p.offsets.assign(E + 1, 0);
+          p.jumps.assign(total ? total : 1, 0.0);
+          check_on(c, epv_download_paths(c, p.init.data(), p.offsets.data(), p.jumps.data()), "epv_download_paths");
+          p.jumps.resize(total);
+          owned[i] = slice_sites(p, q.a - q.lo, q.b - q.lo);
+        } catch (const std::exception &e) { errors[i] = e.what(); }
+      });
+    for (std::thread &w : workers) w.join();
+    for (const std::string &e : errors) if (!e.empty()) throw std::runtime_error(e);
     paths = concat_sites(owned);
     return;
   }

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""config 3 through epievo_est_params_histories with EPV_CLI_TIMING=1: where the iterations' wall
+clock goes, for 1 and 3 contexts per GPU.  python tools/cli_timing.py"""
+import os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from epievo_amd.workloads import simulate, TEST_PARAM_TEXT, TREE_NWK_TEXT   # noqa: E402
+from epievo_amd import host, _build                                        # noqa: E402
+d = tempfile.mkdtemp()
+open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
+open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+model, tree, fp = simulate("tree", 1000000, seed=42)
+host.write_paths(d + "/in.paths", tree.node_names, tree.branches, fp)
+for k in ("1", "3", "1", "3"):
+    t0 = time.time()
+    r = subprocess.run([_build.BIN_DIR + "/epievo_est_params_histories", "-i", "20", "-B", "50", "-L", "10", "-s", "42",
+                        "-o", d + "/out.paths", "-p", d + "/out.param", "-v", d + "/p.param", d + "/t.nwk",
+                        d + "/in.paths"], capture_output=True, text=True,
+                       env=dict(os.environ, EPV_CONTEXTS_PER_GPU=k, EPV_CLI_TIMING="1"))
+    print("contexts %s: %.2f s wall;" % (k, time.time() - t0), [l for l in r.stderr.split("\n") if l.startswith("[TIMING")], flush=True)
