@@ -548,7 +548,12 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
     // one writes back and invalidates the XCD's L2, ~30 us each here
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (f_nseg) {
+    // -DEPV_DBG_SKIP=1 / 2 / 3 leaves out the acceptance / + assembly / + search (instruction counts
+    // per stage: tools/inst_count.sh; the chain then never moves, nothing reads what is missing)
+#ifndef EPV_DBG_SKIP
+#define EPV_DBG_SKIP 0
+#endif
+    if (f_nseg && EPV_DBG_SKIP < 3) {
       EpvCoop W;
       W.len = pool; W.r0 = pool + 64; W.r1 = pool + 128; W.trunc = pool + 192; W.tj = pool + 256;
       uint32_t *u = reinterpret_cast<uint32_t *>(pool + 384);
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
       P2_MARK(7);
-      for (uint32_t i = (uint32_t)lane; i < f_nbt; i += 64u)
+      for (uint32_t i = (uint32_t)lane; i < (EPV_DBG_SKIP < 2 ? f_nbt : 0u); i += 64u)
         epv_seg_assemble_one(S, s_rates, segs, outs, F.bt[f_wave * F.bt_cap + i], F.bfirst[f_wave * F.bt_cap + i], s0,
                              seed_lo, seed_hi, sweep, nielsen);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       A.d = pool + 224 + lane; A.stride = 64u;
       A.j = reinterpret_cast<uint32_t *>(pool + 736) + lane;
       epv_meta_t *mc = reinterpret_cast<epv_meta_t *>(pool + 992) + lane;
-      const unsigned long long lmask = __ballot(f_listed);
+      const unsigned long long lmask = EPV_DBG_SKIP >= 1 ? 0ull : __ballot(f_listed);
       const uint32_t n_listed = (uint32_t)__popcll(lmask);
       const uint32_t my_rank = (uint32_t)__popcll(lmask & ((1ull << lane) - 1ull));
       if (f_listed) s_own[my_rank] = (uint32_t)lane;
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (f_listed) {
+      if (f_listed && EPV_DBG_SKIP < 1) {
         // the owner: Metropolis_Hastings_site :510-533 with the three values (the arithmetic of
         // epv_accept_site, term by term)
         const uint32_t selM = S.sel[site];

@@ -1,9 +1,11 @@
 #!/bin/bash
 # VALU wave-instructions per launch of the MH kernels for library variants (tools/ab_defs.py build):
 #   bash tools/inst_count.sh <tag> NAME ...     (one context, fused phase forced)
+# per stage of the fused phase: python tools/ab_defs.py build "s0=" "s1=-DEPV_DBG_SKIP=1" "s2=-DEPV_DBG_SKIP=2" "s3=-DEPV_DBG_SKIP=3"
 tag=$1; shift
 export TMPDIR=/tmp
 export EPV_FUSED_PHASE=1
+cp profiles/issue.json /tmp/issue.json.keep      # summarize_valu.py adds an entry per call
 for name in "$@"; do
   out=gpurun_out/$tag/$name
   mkdir -p $out
@@ -13,3 +15,4 @@ for name in "$@"; do
   python profiles/summarize_valu.py $(find $out/pmc -name "*results.db" | head -1) scratch_$name $tag 1 2>/dev/null | grep -E "propose2" | cut -d, -f1-3,5,6,10,11
   rm -f profiles/${tag}_pmc_valu_scratch_$name.csv
 done
+cp /tmp/issue.json.keep profiles/issue.json
