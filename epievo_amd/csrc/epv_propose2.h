@@ -109,6 +109,9 @@ __device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long l
   }
 }
 
+#ifndef EPV_P2_DENSE_LIST
+#define EPV_P2_DENSE_LIST 1
+#endif
 #ifndef EPV_PROPOSE2_WAVES
 #define EPV_PROPOSE2_WAVES 3
 #endif
@@ -247,33 +250,74 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
     const uint32_t hbase = inclH - wantH;
 
     P2_MARK(1);
-    // ---- 1. list the heavy segments: forward merge of the neighbours' jumps (Segment.cpp:35-79)
-    if (run && heavy) {
+    // ---- 1. list the heavy segments: forward merge of the neighbours' jumps (Segment.cpp:35-79).
+    //      The merges of different branches are independent, and a lane has a heavy branch at
+    //      about every eighth (lane, node) pair of a short tree: walking the nodes with whichever
+    //      lanes are heavy there kept an eighth of the wave busy.  LDS pool: the heavy (lane, node)
+    //      pairs are listed first (in the node table, which pruning fills only afterwards) and
+    //      then merged one pair per LANE.
+    auto merge_branch = [&](uint32_t owner, uint32_t node, uint32_t hcur, uint64_t jl, uint64_t jr) __attribute__((always_inline)) {
+      const uint32_t b = node - 1u;
+      const uint32_t cL = s_meta[(0u * B + b) * 64u + owner], cR = s_meta[(1u * B + b) * 64u + owner];
+      const uint32_t K = (cL & EPV_NJ_MASK) + (cR & EPV_NJ_MASK) + 1u;
+      PathRef L, R;
+      L.j = S.jumps + jl + (uint64_t)b * Cn; L.nj = cL & EPV_NJ_MASK; L.init = cL >> EPV_INIT_SHIFT;
+      R.j = S.jumps + jr + (uint64_t)b * Cn; R.nj = cR & EPV_NJ_MASK; R.init = cR >> EPV_INIT_SHIFT;
+      uint32_t trip0 = 4u * L.init + R.init, i = 0, j = 0;
+      double seg_start = 0.0;
+      double tl = L.nj ? L.j[0] : EPV_INF, tr = R.nj ? R.j[0] : EPV_INF;
+      for (uint32_t k = 0; k < K; ++k) {
+        const bool last_seg = (k + 1u == K);
+        const bool take_left = tl < tr;
+        const double seg_end = last_seg ? s_blen[node] : (take_left ? tl : tr);
+        double *rec = list + (size_t)(hcur + k) * HREC;
+        rec[LEN_AT] = seg_end - seg_start;
+        rec[INFO_AT] = epv_u2d((uint64_t)trip0 | ((uint64_t)owner << 3) | ((uint64_t)node << 9) | ((uint64_t)k << 21));
+        if (!last_seg) {
+          if (take_left) { trip0 ^= 4u; ++i; tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF; }
+          else { trip0 ^= 1u; ++j; tr = j < R.nj ? R.j[(uint64_t)j * n] : EPV_INF; }
+          seg_start = seg_end;
+        }
+      }
+    };
+    if (!GPOOL && EPV_P2_DENSE_LIST && B > 1u) {      // (a single branch: every lane is its own pair)
+      // 1a. pair words lane | node << 6 | first record << 18 (an LDS pool holds fewer than 2^14 records)
+      uint32_t n_pairs = 0u;
+      if (run && heavy)
+        for (uint32_t b = 0; b < B; ++b)
+          n_pairs += ((s_meta[(0u * B + b) * 64u + lane] | s_meta[(1u * B + b) * 64u + lane]) & EPV_NJ_MASK) ? 1u : 0u;
+      const uint32_t inclP = wave_incl_scan_u32(n_pairs);
+      const uint32_t totP = __shfl(inclP, 63);
+      if (n_pairs) {
+        uint32_t hcur = hbase, at = inclP - n_pairs;
+        for (uint32_t node = 1u; node < S.N; ++node) {
+          const uint32_t b = node - 1u;
+          const uint32_t K = (s_meta[(0u * B + b) * 64u + lane] & EPV_NJ_MASK) + (s_meta[(1u * B + b) * 64u + lane] & EPV_NJ_MASK) + 1u;
+          if (K < 2u) continue;
+          regA[at++] = (uint32_t)lane | (node << 6) | (hcur << 18);
+          hcur += K;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // 1b. one pair per lane
+      for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
+        const uint32_t pidx = p0 + (uint32_t)lane;
+        const uint32_t pr = pidx < totP ? regA[pidx] : 0u;
+        const uint32_t owner = pr & 63u;
+        const uint64_t jl = (uint64_t)__shfl((uint32_t)jbaseL, (int)owner) | ((uint64_t)__shfl((uint32_t)(jbaseL >> 32), (int)owner) << 32);
+        const uint64_t jr = (uint64_t)__shfl((uint32_t)jbaseR, (int)owner) | ((uint64_t)__shfl((uint32_t)(jbaseR >> 32), (int)owner) << 32);
+        if (pidx < totP) merge_branch(owner, (pr >> 6) & 4095u, pr >> 18, jl, jr);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();     // regA goes back to pruning
+    } else if (run && heavy) {
       uint32_t hcur = hbase;
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t b = node - 1u;
-        const uint32_t cL = s_meta[(0u * B + b) * 64u + lane], cR = s_meta[(1u * B + b) * 64u + lane];
-        const uint32_t K = (cL & EPV_NJ_MASK) + (cR & EPV_NJ_MASK) + 1u;
+        const uint32_t K = (s_meta[(0u * B + b) * 64u + lane] & EPV_NJ_MASK) + (s_meta[(1u * B + b) * 64u + lane] & EPV_NJ_MASK) + 1u;
         if (K < 2u) continue;
-        PathRef L, R;
-        L.j = S.jumps + jbaseL + (uint64_t)b * Cn; L.nj = cL & EPV_NJ_MASK; L.init = cL >> EPV_INIT_SHIFT;
-        R.j = S.jumps + jbaseR + (uint64_t)b * Cn; R.nj = cR & EPV_NJ_MASK; R.init = cR >> EPV_INIT_SHIFT;
-        uint32_t trip0 = 4u * L.init + R.init, i = 0, j = 0;
-        double seg_start = 0.0;
-        double tl = L.nj ? L.j[0] : EPV_INF, tr = R.nj ? R.j[0] : EPV_INF;
-        for (uint32_t k = 0; k < K; ++k) {
-          const bool last_seg = (k + 1u == K);
-          const bool take_left = tl < tr;
-          const double seg_end = last_seg ? s_blen[node] : (take_left ? tl : tr);
-          double *rec = list + (size_t)(hcur + k) * HREC;
-          rec[LEN_AT] = seg_end - seg_start;
-          rec[INFO_AT] = epv_u2d((uint64_t)trip0 | ((uint64_t)lane << 3) | ((uint64_t)node << 9) | ((uint64_t)k << 21));
-          if (!last_seg) {
-            if (take_left) { trip0 ^= 4u; ++i; tl = i < L.nj ? L.j[(uint64_t)i * n] : EPV_INF; }
-            else { trip0 ^= 1u; ++j; tr = j < R.nj ? R.j[(uint64_t)j * n] : EPV_INF; }
-            seg_start = seg_end;
-          }
-        }
+        merge_branch((uint32_t)lane, node, hcur, jbaseL, jbaseR);
         hcur += K;
       }
     }
