@@ -202,6 +202,13 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
   // staged, so that the two round trips overlap
   uint32_t selL = 0, selM = 0, selR = 0;
   if (valid) { selL = S.sel[site - 1]; selM = S.sel[site]; selR = S.sel[site + 1]; }
+  // FUSED: the buffers of the columns two sites away, for the acceptance stage's outer triples (they
+  // belong to other colours and do not change in this phase), in the same batch of loads
+  uint32_t selLL = 0, selRR = 0;
+  if (FUSED && valid) {
+    if (S.g0 + site > 1u) selLL = S.sel[site - 2];
+    if (S.g0 + site < S.n_global - 2u) selRR = S.sel[site + 2];
+  }
   for (uint32_t i = threadIdx.x; i < tab_dbl; i += blockDim.x) s_tab[i] = segtab[i];
   stage_constants(S, s_const);
   const double *s_rates = s_const;
@@ -636,21 +643,31 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       const unsigned long long lmask = EPV_DBG_SKIP >= 1 ? 0ull : __ballot(f_listed);
       const uint32_t n_listed = (uint32_t)__popcll(lmask);
       const uint32_t my_rank = (uint32_t)__popcll(lmask & ((1ull << lane) - 1ull));
-      if (f_listed) s_own[my_rank] = (uint32_t)lane;
+      // the owner publishes what its three task lanes need -- the five columns' buffers (known
+      // since the kernel's head) and the capacity flag the assembly may have raised -- and starts
+      // its own loads and its accept uniform before the tasks, whose waits then hide them
+      bool ovf = false;
+      double llh_l = 0.0, llh_m = 0.0, llh_r = 0.0, u_acc = 0.0;
+      if (f_listed) {
+        ovf = S.prop_flag[tid] != 0;
+        llh_l = S.tri[site - 1]; llh_m = S.tri[site]; llh_r = S.tri[site + 1];
+        s_own[my_rank] = (uint32_t)lane | (selLL << 8) | (selL << 9) | ((selM ^ 1u) << 10) | (selR << 11) | (selRR << 12) |
+                         ((ovf ? 1u : 0u) << 13);
+        u_acc = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, 0u, 0u, 0u, 0u).d0;
+      }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      const uint64_t site_lane0 = site - 3u * (uint64_t)lane, tid_lane0 = tid - (uint64_t)lane;
+      const uint64_t site_lane0 = site - 3u * (uint64_t)lane;
       for (uint32_t t = (uint32_t)lane; t < 3u * n_listed; t += 64u) {
-        const uint32_t r = t / 3u, w = t - 3u * r, o = s_own[r];
-        const uint64_t osite = site_lane0 + 3u * (uint64_t)o, otid = tid_lane0 + o;
+        const uint32_t r = t / 3u, w = t - 3u * r, ow = s_own[r], o = ow & 63u;
+        const uint64_t osite = site_lane0 + 3u * (uint64_t)o;
         const uint64_t g = S.g0 + osite;
-        const bool skip = (S.prop_flag[otid] != 0) || (w == 0u && !(g > 1u)) || (w == 2u && !(g < S.n_global - 2u));
+        const bool skip = ((ow >> 13) & 1u) || (w == 0u && !(g > 1u)) || (w == 2u && !(g < S.n_global - 2u));
         double v = 0.0;
         if (!skip) {
           const uint64_t c = osite - 1u + (uint64_t)w;            // centre column of this triple
-          // buffers of the three columns; the proposal (other buffer) stands in for the owner's site
-          uint32_t bl = S.sel[c - 1u], bm = S.sel[c], br = S.sel[c + 1u];
-          if (w == 0u) br ^= 1u; else if (w == 1u) bm ^= 1u; else bl ^= 1u;
+          // buffers of the three columns (bits 8.. of the owner's word: LL, L, proposal, R, RR)
+          const uint32_t bl = (ow >> (8u + w)) & 1u, bm = (ow >> (9u + w)) & 1u, br = (ow >> (10u + w)) & 1u;
           if (F.meta_cache) {
             const uint32_t B2 = S.B;
 #pragma unroll 4
@@ -674,10 +691,6 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       if (f_listed && EPV_DBG_SKIP < 1) {
         // the owner: Metropolis_Hastings_site :510-533 with the three values (the arithmetic of
         // epv_accept_site, term by term)
-        const uint32_t selM = S.sel[site];
-        const uint32_t gsite2 = (uint32_t)(S.g0 + site);
-        const bool ovf = S.prop_flag[tid] != 0;
-        double llh_l = S.tri[site - 1], llh_m = S.tri[site], llh_r = S.tri[site + 1];
         double llr = (S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO) ? S.prop_llr[tid] : 0.0;
         const double llh_l_orig = llh_l, llh_r_orig = llh_r;
         if (!ovf) {
@@ -687,8 +700,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
           if (g < S.n_global - 2u) llh_r = s_res[3u * my_rank + 2u];
         }
         llr += (llh_l + llh_r - llh_l_orig - llh_r_orig);
-        const double u = epv_keyed_block(seed_lo, seed_hi, gsite2, sweep, 0u, 0u, 0u, 0u).d0;
-        bool acc = (llr >= 0.0) || (u < epv_exp(llr));
+        bool acc = (llr >= 0.0) || (u_acc < epv_exp(llr));
         if (ovf) { acc = false; overflowed = true; }
         if (acc) {
           S.sel[site] = (uint8_t)(selM ^ 1u);
