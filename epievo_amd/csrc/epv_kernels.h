@@ -33,7 +33,20 @@
 // ------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ int epv_lane() { return (int)(threadIdx.x & 63); }
 
+// inclusive prefix sum over the 64 lanes (all active).  DPP: shifts by 1, 2, 4, 8 inside the
+// 16-lane rows (lanes shifted in from outside a row read 0), then lane 15 of rows 0 and 2 into rows
+// 1 and 3 (row_bcast:15, row mask 0b1010) and lane 31 into rows 2 and 3 (row_bcast:31, 0b1100):
+// six v_add_u32_dpp instead of six ds_bpermute with index arithmetic and predicated adds
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+#ifndef EPV_SCAN_BPERMUTE
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+  return v;
+#else
   const int lane = epv_lane();
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -41,6 +54,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     if (lane >= d) v += o;
   }
   return v;
+#endif
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
