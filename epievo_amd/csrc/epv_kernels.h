@@ -33,6 +33,11 @@
 // ------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ int epv_lane() { return (int)(threadIdx.x & 63); }
 
+// the value of lane `src` in every lane, src wave-uniform: one v_readlane_b32 (the result lives in a
+// scalar register) instead of a ds_bpermute with a per-lane index
+__device__ __forceinline__ uint32_t epv_bcast(uint32_t v, int src) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+}
 // inclusive prefix sum over the 64 lanes (all active).  DPP: shifts by 1, 2, 4, 8 inside the
 // 16-lane rows (lanes shifted in from outside a row read 0), then lane 15 of rows 0 and 2 into rows
 // 1 and 3 (row_bcast:15, row mask 0b1010) and lane 31 into rows 2 and 3 (row_bcast:31, 0b1100):
@@ -665,13 +670,13 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
             const uint32_t mineB = (uint32_t)__popcll(mine_reg & multi);
             const uint32_t mineA = (uint32_t)__popcll(mine_reg) - mineB;
             const uint32_t inclA = wave_incl_scan_u32(mineA), inclB = wave_incl_scan_u32(mineB);
-            const uint32_t totalA = __shfl(inclA, 63), totalB = __shfl(inclB, 63);
+            const uint32_t totalA = epv_bcast(inclA, 63), totalB = epv_bcast(inclB, 63);
             if (totalA | totalB) {
               unsigned long long base = 0ull;
               if (lane == 0)
                 base = atomicAdd(&counters[EPV_CNT_IDX(reg ? EPV_CNT_TASKS2 : EPV_CNT_TASKS, shard)],
                                  (unsigned long long)totalA | ((unsigned long long)totalB << 32));
-              const uint32_t baseA = __shfl((uint32_t)base, 0), baseB = __shfl((uint32_t)(base >> 32), 0);
+              const uint32_t baseA = epv_bcast((uint32_t)base, 0), baseB = epv_bcast((uint32_t)(base >> 32), 0);
               unsigned long long *region = S.tasks + ((unsigned long long)shard * 2u + reg) * S.task_cap;
               unsigned long long slotA = (unsigned long long)baseA + (inclA - mineA);
               unsigned long long slotB = S.task_cap - 1ull - ((unsigned long long)baseB + (inclB - mineB));
@@ -1106,14 +1111,14 @@ __global__ __launch_bounds__(256) void epv_init_tasks_kernel(EpvDev S, uint32_t 
   }
   const uint32_t mine = valid ? 1u : 0u;
   const uint32_t incl = wave_incl_scan_u32(mine);
-  const uint32_t total = __shfl(incl, 63);
+  const uint32_t total = epv_bcast(incl, 63);
   if (total) {
     const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
     unsigned long long base = 0ull;
     if (lane == 0)
       base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)], (unsigned long long)total);
-    base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0) << 32) |
-           (unsigned long long)__shfl((uint32_t)base, 0);
+    base = ((unsigned long long)epv_bcast((uint32_t)(base >> 32), 0) << 32) |
+           (unsigned long long)epv_bcast((uint32_t)base, 0);
     if (valid) S.tasks[(unsigned long long)shard * 2u * S.task_cap + base + (incl - mine)] = site;
   }
 }
@@ -1315,14 +1320,14 @@ __global__ __launch_bounds__(64) void epv_indep_propose_kernel(EpvDev S, const E
     if ((b & 63u) == 63u || node + 1u == S.N) {
       const uint32_t mine = (uint32_t)__popcll(dirty);
       const uint32_t incl_t = wave_incl_scan_u32(mine);
-      const uint32_t total = __shfl(incl_t, 63);
+      const uint32_t total = epv_bcast(incl_t, 63);
       if (total) {
         unsigned long long base = 0ull;
         const uint32_t shard = blockIdx.x & (EPV_SHARDS - 1u);
         if (lane == 0)
           base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)], (unsigned long long)total);
-        base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0) << 32) |
-               (unsigned long long)__shfl((uint32_t)base, 0);
+        base = ((unsigned long long)epv_bcast((uint32_t)(base >> 32), 0) << 32) |
+               (unsigned long long)epv_bcast((uint32_t)base, 0);
         unsigned long long slot = (unsigned long long)shard * 2u * S.task_cap + base + (incl_t - mine);
         unsigned long long d = dirty;
         while (d) {

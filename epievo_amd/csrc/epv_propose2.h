@@ -87,13 +87,13 @@ __device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long l
     const uint32_t mineB = (uint32_t)__popcll(mine_reg & multi);
     const uint32_t mineA = (uint32_t)__popcll(mine_reg) - mineB;
     const uint32_t inclA = wave_incl_scan_u32(mineA), inclB = wave_incl_scan_u32(mineB);
-    const uint32_t totalA = __shfl(inclA, 63), totalB = __shfl(inclB, 63);
+    const uint32_t totalA = epv_bcast(inclA, 63), totalB = epv_bcast(inclB, 63);
     if (totalA | totalB) {
       unsigned long long base = 0ull;
       if (lane == 0)
         base = atomicAdd(&counters[EPV_CNT_IDX(reg ? EPV_CNT_TASKS2 : EPV_CNT_TASKS, shard)],
                          (unsigned long long)totalA | ((unsigned long long)totalB << 32));
-      const uint32_t baseA = __shfl((uint32_t)base, 0), baseB = __shfl((uint32_t)(base >> 32), 0);
+      const uint32_t baseA = epv_bcast((uint32_t)base, 0), baseB = epv_bcast((uint32_t)(base >> 32), 0);
       unsigned long long *region = S.tasks + ((unsigned long long)shard * 2u + reg) * S.task_cap;
       unsigned long long slotA = (unsigned long long)baseA + (inclA - mineA);
       unsigned long long slotB = S.task_cap - 1ull - ((unsigned long long)baseB + (inclB - mineB));
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
                                        : (2u * inclR + HREC * inclH <= pool_dbl));
     const unsigned long long rmask = __ballot(run);
     const int hi_lane = rmask ? 63 - __clzll((long long)rmask) : 0;
-    const uint32_t totR = rmask ? __shfl(inclR, hi_lane) : 0u, totH = rmask ? __shfl(inclH, hi_lane) : 0u;
+    const uint32_t totR = rmask ? epv_bcast(inclR, hi_lane) : 0u, totH = rmask ? epv_bcast(inclH, hi_lane) : 0u;
     constexpr size_t RS = GPOOL ? 128u : 2u;   // doubles between consecutive records of a lane
     double *my = GPOOL ? pool + (size_t)lane * 2u : pool + (size_t)(inclR - wantR) * 2u;
     double *list = GPOOL ? pool + (size_t)pool_dbl * 128u : pool + (size_t)totR * 2u;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         for (uint32_t b = 0; b < B; ++b)
           n_pairs += ((s_meta[(0u * B + b) * 64u + lane] | s_meta[(1u * B + b) * 64u + lane]) & EPV_NJ_MASK) ? 1u : 0u;
       const uint32_t inclP = wave_incl_scan_u32(n_pairs);
-      const uint32_t totP = __shfl(inclP, 63);
+      const uint32_t totP = epv_bcast(inclP, 63);
       if (n_pairs) {
         uint32_t hcur = hbase, at = inclP - n_pairs;
         for (uint32_t node = 1u; node < S.N; ++node) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         const bool cand = dirty_b && Kb <= 64u;
         const uint32_t wS = cand ? nds : 0u, wB = cand ? 1u : 0u;
         const uint32_t inclS = wave_incl_scan_u32(wS), inclB = wave_incl_scan_u32(wB);
-        const uint32_t totS = __shfl(inclS, 63), totB = __shfl(inclB, 63);
+        const uint32_t totS = epv_bcast(inclS, 63), totB = epv_bcast(inclB, 63);
         if (totB) {
           const uint32_t shard = my_shard;
           uint32_t bS, bB;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
             if (lane == 0)
               base = atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_SEG, shard)],
                                (unsigned long long)totS | ((unsigned long long)totB << 32));
-            bS = __shfl((uint32_t)base, 0); bB = __shfl((uint32_t)(base >> 32), 0);
+            bS = epv_bcast((uint32_t)base, 0); bB = epv_bcast((uint32_t)(base >> 32), 0);
           }
           if (cand) {
             const uint64_t i0 = (uint64_t)bS + (inclS - wS), j0 = (uint64_t)bB + (inclB - 1u);
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         if (lane == 0)
           base = atomicAdd(&counters[EPV_CNT_IDX(parity ? EPV_CNT_ALIST1 : EPV_CNT_ALIST0, shard)],
                            (unsigned long long)__popcll(lm));
-        const uint32_t b0 = __shfl((uint32_t)base, 0);
+        const uint32_t b0 = epv_bcast((uint32_t)base, 0);
         if (to_list)
           S.alist[(uint64_t)shard * S.alist_cap + b0 + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = (uint32_t)tid;
       }
