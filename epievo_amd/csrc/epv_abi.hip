@@ -41,7 +41,10 @@ struct epv_ctx {
   unsigned long long *h_counters = nullptr;  // pinned staging for the sharded counters
   double *d_partial[2] = {nullptr, nullptr};  // tree-reduction ping-pong
   uint64_t partial_cap[2] = {0, 0};   // doubles allocated in d_partial[0], [1]
-  double *d_jd_acc = nullptr;  // [B*16] accumulated over batch sweeps
+  unsigned long long *d_sweep_tot = nullptr;  // [sweep][B*16] integer statistics of the batch sweeps
+  uint64_t sweep_tot_cap = 0;                 // sweeps allocated
+  double *d_statscale = nullptr;              // [N] 2^k_b of the fixed-point dwell times (epv_suffstat_kernel)
+  std::vector<double> statscale;              // host copy; refreshed when the tree or the genome length changes
   double *d_scale = nullptr;
   double *d_lvl = nullptr;      // level outputs of epv_reduce_blocks (all batch sweeps at once)
   uint64_t lvl_cap = 0;
@@ -337,28 +340,106 @@ int phase_range(epv_ctx *c, uint64_t *lo, uint64_t *hi) {
   return EPV_OK;
 }
 
-// J/D of the current paths into d_partial[x][0..V); returns the buffer index via *which
-int launch_suffstats(epv_ctx *c, int *which) {
-  int rc = ensure_partials(c);
-  if (rc) return rc;
-  const uint64_t nb = (c->S.n + 255u) / 256u;
+// ---- exact statistics.  The dwell times of branch b are summed as integers rint(dt * 2^k_b),
+//   k_b = min(61 - e(n_global * T_b), 50 - e(T_b)),   e(x) = the frexp exponent (x < 2^e):
+// a whole genome's sum stays below 2^61, a single term below 2^50 (epv_stat_fix rounds with one
+// add).  oracle/epv_oracle.c (stat_scale_exp) makes the same choice independently.
+int stat_scale_exp(uint64_t n_global, double T) {
+  if (!(T > 0.0) || !std::isfinite(T)) return 0;
+  int e_t = 0, e_nt = 0;
+  (void)std::frexp(T, &e_t);
+  (void)std::frexp((double)n_global * T, &e_nt);
+  int k = std::min(61 - e_nt, 50 - e_t);
+  return std::max(-1000, std::min(1000, k));
+}
+// 2^k_b of every branch on the device, refreshed when the branch lengths or the genome length changed
+int ensure_stat_scale(epv_ctx *c) {
+  std::vector<double> sc(c->S.N, 1.0);
+  for (uint32_t b = 1; b < c->S.N; ++b) sc[b] = std::ldexp(1.0, stat_scale_exp(c->S.n_global, c->blen[b]));
+  if (sc == c->statscale) return EPV_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(c->d_statscale, sc.data(), sizeof(double) * c->S.N, hipMemcpyHostToDevice));
+  c->statscale = sc;
+  return EPV_OK;
+}
+int ensure_sweep_tot(epv_ctx *c, uint64_t sweeps) {
+  if (sweeps <= c->sweep_tot_cap) return EPV_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  dfree(c->d_sweep_tot);
+  c->sweep_tot_cap = 0;
+  HIP_TRY(c, hipMalloc(&c->d_sweep_tot, sweeps * c->S.B * 16u * sizeof(unsigned long long)));
+  c->sweep_tot_cap = sweeps;
+  return EPV_OK;
+}
+void launch_isum(epv_ctx *c, const void *in, uint64_t m, uint64_t G, uint64_t in_row_stride, uint64_t in_z_stride,
+                 void *out, uint64_t out_row_stride, uint64_t out_z_stride, uint64_t n_out_rows, uint64_t Z) {
   const uint32_t V = c->S.B * 16u;
-  uint64_t own_lo = 0, own_hi = 0;
-  owned_range(c, &own_lo, &own_hi);
-  hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)nb, c->S.B), dim3(256), const_lds_bytes(c->S.N),
-                     c->stream, c->S, own_lo, own_hi, (uint64_t)0, c->d_partial[0]);
-  uint64_t m = nb;
-  int cur = 0;
-  while (m > 1) {
-    const uint64_t mb = (m + 255u) / 256u;
-    hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb, V / 16u), dim3(256), 0, c->stream,
-                       c->d_partial[cur], m, V, c->d_partial[cur ^ 1]);
-    m = mb;
-    cur ^= 1;
+  hipLaunchKernelGGL(epv_isum_kernel, dim3(V / 16u, (unsigned)n_out_rows, (unsigned)Z), dim3(256), 0, c->stream,
+                     (const unsigned long long *)in, m, V, G, in_row_stride, in_z_stride, (unsigned long long *)out,
+                     out_row_stride, out_z_stride);
+}
+// integer J/D of nb_total blocks x Z slices ([z][block][V] at d_blocks) -> d_sweep_tot[slot0 + z][V]
+int reduce_blocks_to_tot(epv_ctx *c, const void *d_blocks, uint64_t nb_total, uint64_t Z, uint64_t slot0) {
+  const uint32_t V = c->S.B * 16u;
+  int rc = ensure_sweep_tot(c, slot0 + Z);
+  if (rc) return rc;
+  if (Z > 65535u) return fail(c, EPV_ERR_ARG, "too many batch sweeps for one launch");
+  unsigned long long *out = c->d_sweep_tot + slot0 * V;
+  if (nb_total <= 1024u) {
+    launch_isum(c, d_blocks, nb_total, 0u, V, nb_total * V, out, 0u, V, 1u, Z);
+  } else {
+    // two stages: groups of 64 blocks (wide grid), then their sums
+    const uint64_t m1 = (nb_total + 63u) / 64u;
+    if (m1 > 65535u) return fail(c, EPV_ERR_ARG, "more than 2^22 blocks per context");
+    if (Z * m1 * V > c->lvl_cap) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      dfree(c->d_lvl);
+      c->lvl_cap = 0;
+      HIP_TRY(c, hipMalloc(&c->d_lvl, Z * m1 * V * sizeof(double)));
+      c->lvl_cap = Z * m1 * V;
+    }
+    launch_isum(c, d_blocks, nb_total, 64u, V, nb_total * V, c->d_lvl, V, m1 * V, m1, Z);
+    launch_isum(c, c->d_lvl, m1, 0u, V, m1 * V, out, 0u, V, 1u, Z);
   }
   HIP_TRY(c, hipGetLastError());
-  *which = cur;
   return EPV_OK;
+}
+// the integer totals of `batch` sweeps (d_sweep_tot[0 .. batch)) -> J, D as run_mcmc returns them
+// (SingleSiteSampler.cpp:576-594): every sweep's statistics become doubles -- J = the count,
+// D = the integer * 2^-k_b, exact but for the one rounding of int64 -> double -- and are added up
+// sweep by sweep in fp64 like J_all_sites += J_one_site, then divided by the batch size
+int finish_stats(epv_ctx *c, uint64_t batch, int average, double *J, double *D) {
+  const uint32_t V = c->S.B * 16u;
+  std::vector<long long> tot(batch * V);
+  HIP_TRY(c, hipMemcpyAsync(tot.data(), c->d_sweep_tot, batch * V * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const double nb = average ? (double)batch : 1.0;
+  for (uint32_t b = 0; b < c->S.B; ++b) {
+    const double inv = 1.0 / c->statscale[b + 1u];     // a power of two: exact
+    for (int k = 0; k < 8; ++k) {
+      double aj = 0.0, ad = 0.0;
+      for (uint64_t w = 0; w < batch; ++w) {
+        aj += (double)tot[w * V + b * 16u + k];
+        ad += (double)tot[w * V + b * 16u + 8u + k] * inv;
+      }
+      J[b * 8 + k] = aj / nb;
+      D[b * 8 + k] = ad / nb;
+    }
+  }
+  return EPV_OK;
+}
+
+// integer J/D of the current paths over the owned range into d_sweep_tot[slot]
+int launch_suffstats(epv_ctx *c, uint64_t slot) {
+  int rc = ensure_partials(c);
+  if (rc) return rc;
+  if ((rc = ensure_stat_scale(c))) return rc;
+  const uint64_t nb = (c->S.n + 255u) / 256u;
+  uint64_t own_lo = 0, own_hi = 0;
+  owned_range(c, &own_lo, &own_hi);
+  hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)nb, (c->S.B + EPV_STAT_BCH - 1u) / EPV_STAT_BCH), dim3(256), 0,
+                     c->stream, c->S, own_lo, own_hi, (uint64_t)0, c->d_statscale, (unsigned long long *)c->d_partial[0]);
+  return reduce_blocks_to_tot(c, c->d_partial[0], nb, 1u, slot);
 }
 
 int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
@@ -574,7 +655,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_jd_acc); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_segtab);
+  dfree(c->d_counters); dfree(c->d_sweep_tot); dfree(c->d_statscale); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_segtab);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->stream);
@@ -598,11 +679,12 @@ EPV_API int epv_set_tree(epv_ctx *c, int n_nodes, const uint32_t *parent_ids,
   c->parent.assign(parent_ids, parent_ids + n_nodes);
   c->subtree.assign(subtree_sizes, subtree_sizes + n_nodes);
   c->blen.assign(branches, branches + n_nodes);
-  dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen); dfree(c->d_jd_acc); dfree(c->d_scale);
+  dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen); dfree(c->d_statscale); dfree(c->d_scale);
+  c->statscale.clear();
   HIP_TRY(c, hipMalloc(&c->d_parent, sizeof(uint32_t) * n_nodes));
   HIP_TRY(c, hipMalloc(&c->d_subtree, sizeof(uint32_t) * n_nodes));
   HIP_TRY(c, hipMalloc(&c->d_blen, sizeof(double) * n_nodes));
-  HIP_TRY(c, hipMalloc(&c->d_jd_acc, sizeof(double) * (n_nodes - 1) * 16));
+  HIP_TRY(c, hipMalloc(&c->d_statscale, sizeof(double) * n_nodes));
   HIP_TRY(c, hipMalloc(&c->d_scale, sizeof(double) * n_nodes));
   HIP_TRY(c, hipMemcpy(c->d_parent, parent_ids, sizeof(uint32_t) * n_nodes, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_subtree, subtree_sizes, sizeof(uint32_t) * n_nodes, hipMemcpyHostToDevice));
@@ -1090,7 +1172,6 @@ EPV_API int epv_run_mcmc_sums(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint
   if (rc) return rc;
   if (!J || !D || batch == 0) return fail(c, EPV_ERR_ARG, "bad run_mcmc arguments");
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint32_t V = c->S.B * 16u;
   uint32_t sweep = sweep_base;
   for (uint64_t w = 0; w < burn_in; ++w, ++sweep) {
     for (int colour = 0; colour < 3; ++colour)
@@ -1099,27 +1180,17 @@ EPV_API int epv_run_mcmc_sums(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint
   }
   uint64_t base = 0;
   if ((rc = current_accepts(c, &base))) return rc;
-  HIP_TRY(c, hipMemsetAsync(c->d_jd_acc, 0, V * sizeof(double), c->stream));
+  if ((rc = ensure_sweep_tot(c, batch))) return rc;
   for (uint64_t w = 0; w < batch; ++w, ++sweep) {
     for (int colour = 0; colour < 3; ++colour)
       if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
     ++c->n_sweeps;
-    int which = 0;
-    if ((rc = launch_suffstats(c, &which))) return rc;
-    hipLaunchKernelGGL(epv_accumulate_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream,
-                       c->d_jd_acc, c->d_partial[which], V);
+    if ((rc = launch_suffstats(c, w))) return rc;
   }
   HIP_TRY(c, hipGetLastError());
-  std::vector<double> jd(V);
-  HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_jd_acc, V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   rc = finish_mcmc(c, n_accepted, base);  // synchronises the stream
-  const double nb = average ? (double)batch : 1.0;
-  for (uint32_t b = 0; b < c->S.B; ++b)
-    for (int k = 0; k < 8; ++k) {
-      J[b * 8 + k] = jd[b * 16 + k] / nb;       // batch average, SingleSiteSampler.cpp:589-594
-      D[b * 8 + k] = jd[b * 16 + 8 + k] / nb;
-    }
-  return rc;
+  const int src = finish_stats(c, batch, average, J, D);
+  return rc ? rc : src;
 }
 
 // ---- several shards on ONE GPU (epievo_amd.parallel.LocalGroup): each shard writes the
@@ -1169,6 +1240,7 @@ EPV_API int epv_run_mcmc_blocks(epv_ctx *c, uint64_t burn_in, uint64_t batch, ui
   if (block_offset + (int64_t)blk_lo < 0 || block_offset + (int64_t)blk_hi >= (int64_t)nb_total)
     return fail(c, EPV_ERR_ARG, "owned blocks exceed the group's block buffer");
   if ((c->S.g0 & 255u) != 0u) return fail(c, EPV_ERR_ARG, "the shard must start on a 256-site block of the genome");
+  if ((rc = ensure_stat_scale(c))) return rc;
   uint32_t sweep = sweep_base;
   for (uint64_t w = 0; w < burn_in; ++w, ++sweep) {
     for (int colour = 0; colour < 3; ++colour)
@@ -1181,9 +1253,9 @@ EPV_API int epv_run_mcmc_blocks(epv_ctx *c, uint64_t burn_in, uint64_t batch, ui
     for (int colour = 0; colour < 3; ++colour)
       if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
     ++c->n_sweeps;
-    hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)(blk_hi - blk_lo + 1u), c->S.B), dim3(256),
-                       const_lds_bytes(c->S.N), c->stream, c->S, own_lo, own_hi, blk_lo,
-                       d_blocks + (w * nb_total + (uint64_t)(block_offset + (int64_t)blk_lo)) * V);
+    hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)(blk_hi - blk_lo + 1u), (c->S.B + EPV_STAT_BCH - 1u) / EPV_STAT_BCH),
+                       dim3(256), 0, c->stream, c->S, own_lo, own_hi, blk_lo, c->d_statscale,
+                       (unsigned long long *)d_blocks + (w * nb_total + (uint64_t)(block_offset + (int64_t)blk_lo)) * V);
   }
   HIP_TRY(c, hipGetLastError());
   return finish_mcmc(c, n_accepted, base);  // synchronises the stream
@@ -1194,45 +1266,10 @@ EPV_API int epv_reduce_blocks(epv_ctx *c, const double *d_blocks, uint64_t nb_to
   if (!c || !d_blocks || !J || !D || !nb_total || !batch) return EPV_ERR_ARG;
   if (!c->have_tree) return fail(c, EPV_ERR_STATE, "epv_set_tree must come first");
   HIP_TRY(c, hipSetDevice(c->device));
-  int rc = ensure_partials(c, nb_total);
+  int rc = ensure_stat_scale(c);
   if (rc) return rc;
-  const uint32_t V = c->S.B * 16u;
-  // all `batch` reductions level by level (grid z = sweep), then one sequential accumulation
-  const uint64_t mb1 = (nb_total + 255u) / 256u, mb2 = (mb1 + 255u) / 256u;
-  const uint64_t need = batch * (mb1 + mb2) * V;
-  if (need > c->lvl_cap) {
-    dfree(c->d_lvl);
-    c->lvl_cap = 0;
-    HIP_TRY(c, hipMalloc(&c->d_lvl, need * sizeof(double)));
-    c->lvl_cap = need;
-  }
-  const double *in = d_blocks;
-  uint64_t m = nb_total, in_stride = nb_total * V;
-  double *outs[2] = {c->d_lvl, c->d_lvl + batch * mb1 * V};
-  int cur = 0;
-  while (m > 1) {
-    const uint64_t mb = (m + 255u) / 256u;
-    if (cur > 1) return fail(c, EPV_ERR_ARG, "more than 2^24 blocks per group");
-    hipLaunchKernelGGL(epv_tree_reduce_kernel, dim3((unsigned)mb, V / 16u, (unsigned)batch), dim3(256), 0, c->stream,
-                       in, m, V, outs[cur], in_stride, mb * V);
-    in = outs[cur];
-    in_stride = mb * V;
-    m = mb;
-    ++cur;
-  }
-  hipLaunchKernelGGL(epv_accumulate_seq_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream, c->d_jd_acc, in, V,
-                     batch, in_stride);
-  HIP_TRY(c, hipGetLastError());
-  std::vector<double> jd(V);
-  HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_jd_acc, V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  const double nb = average ? (double)batch : 1.0;
-  for (uint32_t b = 0; b < c->S.B; ++b)
-    for (int k = 0; k < 8; ++k) {
-      J[b * 8 + k] = jd[b * 16 + k] / nb;
-      D[b * 8 + k] = jd[b * 16 + 8 + k] / nb;
-    }
-  return EPV_OK;
+  if ((rc = reduce_blocks_to_tot(c, d_blocks, nb_total, batch, 0u))) return rc;
+  return finish_stats(c, batch, average, J, D);
 }
 
 // ---- statistics of a genome sharded over several GPUs: every GPU turns the level-0 partials
@@ -1249,9 +1286,8 @@ EPV_API int epv_blocks_to_rows(epv_ctx *c, const double *d_blocks, uint64_t nb_t
   const uint64_t n_rows = (nb_total + row_blocks - 1u) / row_blocks;
   if (n_rows > 65535u || batch > 65535u) return fail(c, EPV_ERR_ARG, "too many rows or batch sweeps for one launch");
   // in: [w][block][V]   out: [row][w][V] (a GPU's rows are one contiguous piece of the gathered buffer)
-  hipLaunchKernelGGL(epv_rowsum_kernel, dim3((V + 255u) / 256u, (unsigned)n_rows, (unsigned)batch), dim3(256), 0,
-                     c->stream, d_blocks, nb_total, V, (uint64_t)row_blocks, (uint64_t)V, nb_total * V, d_rows,
-                     batch * V, (uint64_t)V);
+  launch_isum(c, d_blocks, nb_total, (uint64_t)row_blocks, (uint64_t)V, nb_total * V, d_rows, batch * V, (uint64_t)V,
+              n_rows, batch);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return EPV_OK;
@@ -1264,29 +1300,13 @@ EPV_API int epv_reduce_rows(epv_ctx *c, const double *d_rows, uint64_t n_rows, u
   if (batch > 65535u) return fail(c, EPV_ERR_ARG, "too many batch sweeps for one launch");
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t V = c->S.B * 16u;
-  if (batch * V > c->lvl_cap) {
-    dfree(c->d_lvl);
-    c->lvl_cap = 0;
-    HIP_TRY(c, hipMalloc(&c->d_lvl, batch * V * sizeof(double)));
-    c->lvl_cap = batch * V;
-  }
-  // per batch sweep the total over all rows (zero padded to a power of two), then the
-  // sequential accumulation over the sweeps exactly as run_mcmc adds them
-  hipLaunchKernelGGL(epv_rowsum_kernel, dim3((V + 255u) / 256u, 1u, (unsigned)batch), dim3(256), 0, c->stream,
-                     d_rows, n_rows, V, (uint64_t)0, batch * V, (uint64_t)V, c->d_lvl, (uint64_t)0, (uint64_t)V);
-  hipLaunchKernelGGL(epv_accumulate_seq_kernel, dim3((V + 255u) / 256u), dim3(256), 0, c->stream, c->d_jd_acc,
-                     c->d_lvl, V, batch, (uint64_t)V);
+  int rc = ensure_stat_scale(c);
+  if (rc) return rc;
+  if ((rc = ensure_sweep_tot(c, batch))) return rc;
+  // per batch sweep the integer total over all rows ([row][sweep][V]), then the host's accumulation
+  launch_isum(c, d_rows, n_rows, 0u, batch * V, (uint64_t)V, c->d_sweep_tot, 0u, (uint64_t)V, 1u, batch);
   HIP_TRY(c, hipGetLastError());
-  std::vector<double> jd(V);
-  HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_jd_acc, V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  const double nb = average ? (double)batch : 1.0;
-  for (uint32_t b = 0; b < c->S.B; ++b)
-    for (int k = 0; k < 8; ++k) {
-      J[b * 8 + k] = jd[b * 16 + k] / nb;
-      D[b * 8 + k] = jd[b * 16 + 8 + k] / nb;
-    }
-  return EPV_OK;
+  return finish_stats(c, batch, average, J, D);
 }
 
 // the same on the buffer an all-gather of equally sized pieces leaves behind:
@@ -1331,18 +1351,8 @@ EPV_API int epv_get_sufficient_statistics(epv_ctx *c, double *J, double *D) {
   int rc = check_ready(c, false);
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
-  int which = 0;
-  if ((rc = launch_suffstats(c, &which))) return rc;
-  const uint32_t V = c->S.B * 16u;
-  std::vector<double> jd(V);
-  HIP_TRY(c, hipMemcpyAsync(jd.data(), c->d_partial[which], V * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (uint32_t b = 0; b < c->S.B; ++b)
-    for (int k = 0; k < 8; ++k) {
-      J[b * 8 + k] = jd[b * 16 + k];
-      D[b * 8 + k] = jd[b * 16 + 8 + k];
-    }
-  return EPV_OK;
+  if ((rc = launch_suffstats(c, 0u))) return rc;
+  return finish_stats(c, 1u, 0, J, D);
 }
 
 EPV_API int epv_scale_jump_times(epv_ctx *c, const double *new_branches) {

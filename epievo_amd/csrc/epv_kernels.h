@@ -1378,52 +1378,151 @@ __global__ __launch_bounds__(256) void epv_reset_kernel(EpvDev S) {
 }
 
 // =========================================================================
-//  sufficient statistics: per-branch J[8], D[8] over the triples centred at local
-//  sites [first,last], reduced in the canonical balanced-binary-tree order over the
-//  local site index (lane butterfly -> 4 waves through LDS -> block partials ->
-//  epv_tree_reduce_kernel levels).  partial layout: [block][b][16] (J then D).
+//  sufficient statistics (get_sufficient_statistics, ParamEstimation.cpp:92-114;
+//  add_sufficient_statistics, Path.cpp:206-301): per-branch J[8], D[8] over the triples centred
+//  at the owned local sites, as EXACT integers -- J as counts, every dwell time as the
+//  fixed-point integer rint(dt * 2^k_b) (statscale[b + 1] = 2^k_b from the host, see
+//  stat_scale_exp in epv_abi.hip and oracle/epv_oracle.c).  int64 sums are associative, so the
+//  totals do not depend on the launch shape, on how a genome is cut into contexts and GPUs, or on
+//  the order atomics land in; the host turns them back into doubles.
+//
+//  One block = 256 consecutive sites, all branches (blockIdx.y: chunks of EPV_STAT_BCH).
+//  Per branch a lane loads ITS site's meta word, the neighbours' come through LDS.  86 % of the
+//  (site, branch) pairs of a short tree have no jump in the triple: D[ctx] += T, i.e. a
+//  histogram of the 3-bit context -- three ballots and eight popcounts per wave, multiplied by
+//  fix(T) once per block.  The other pairs are queued in an LDS ring and merged with DENSE lanes,
+//  256 at a time (walking the branches with whichever lanes have a jump there kept one lane in
+//  seven busy), their events added to the block's LDS accumulators with ds_add_u64.
+//  partial layout: [block][b][16] int64 (J then D).
 // =========================================================================
+#define EPV_STAT_BCH 32u
+struct AccExact {
+  unsigned long long *acc;   // this branch's 16 LDS words: J[8], D[8]
+  double scale;              // 2^k_b
+};
+// rint(x) for |x| < 2^51 as an integer: adding 1.5 * 2^52 leaves it in the low mantissa bits
+// (round to nearest even, what llrint does on the host)
+__device__ __forceinline__ unsigned long long epv_stat_fix(double dt, double scale) {
+  const double y = dt * scale + 6755399441055744.0;
+  return epv_d2u(y) - 0x4338000000000000ull;
+}
+__device__ __forceinline__ void acc_add(AccExact &A, int ctx, double dt, bool mid) {
+  atomicAdd(&A.acc[8 + ctx], epv_stat_fix(dt, A.scale));
+  if (mid) atomicAdd(&A.acc[ctx], 1ull);
+}
 
-__global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t first,
-                                                           uint64_t last, uint64_t block0,
-                                                           double *partial) {
-  extern __shared__ __attribute__((aligned(16))) double s_mem[];
-  __shared__ double s_part[4][16];
-  stage_constants(S, s_mem);
-  const double *s_blen = s_mem + 20;
+__global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t first, uint64_t last, uint64_t block0,
+                                                           const double *statscale, unsigned long long *partial) {
+  __shared__ unsigned long long s_acc[EPV_STAT_BCH * 16u];
+  __shared__ uint32_t s_cnt[EPV_STAT_BCH * 8u];     // triples without a jump, per (branch, context)
+  __shared__ epv_meta_t s_meta[2][258];
+  __shared__ uint8_t s_sel[258];
+  __shared__ uint32_t s_ring[512];                  // thread | local branch << 8
+  __shared__ uint32_t s_tail;
+  const uint32_t t = threadIdx.x;
   const int lane = epv_lane();
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t b = blockIdx.y;          // one branch per block row: B x more blocks in flight
+  const uint32_t B = S.B;
+  const uint32_t b_lo = blockIdx.y * EPV_STAT_BCH, b_hi = (b_lo + EPV_STAT_BCH < B) ? b_lo + EPV_STAT_BCH : B;
+  const uint64_t n = S.n, Bn = (uint64_t)B * n;
   // block0: first 256-site block to process (partial[] is relative to it)
-  const uint64_t site = (block0 + blockIdx.x) * blockDim.x + threadIdx.x;
-  const bool on = site >= first && site <= last && site >= 1 && site + 1 < S.n;
-#ifdef EPV_SUFFSTAT_LDS
-  // per-context sums in LDS columns (one per thread): a runtime-indexed update costs ~6
-  // instructions instead of the ~40 of the register select chain
-  __shared__ double s_accd[8 * 256];
-  __shared__ uint32_t s_accj[8 * 256];
-  AccLds A;
-  A.d = s_accd + threadIdx.x; A.j = s_accj + threadIdx.x; A.stride = 256u;
-#else
-  Acc8 A;
-#endif
-  acc_clear(A);
-  if (on) {
-    const uint32_t sl = S.sel[site - 1], sm = S.sel[site], sr = S.sel[site + 1];
-    const PathRef L = path_ref(S, sl, b, site - 1), M = path_ref(S, sm, b, site),
-                  R = path_ref(S, sr, b, site + 1);
-    merge3(L, M, R, S.n, s_blen[b + 1], A);
-  }
-  double v[16];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) { v[c] = (double)acc_j(A, c); v[8 + c] = acc_d(A, c); }
-  int idx;
-  const double tot = wave_tree_sum16(v, lane, idx);
-  if (lane < 16) s_part[wave][idx] = tot;
+  const uint64_t site0 = (block0 + blockIdx.x) * 256u, site = site0 + t;
+  const bool on = site >= first && site <= last && site >= 1 && site + 1 < n;
+  for (uint32_t i = t; i < EPV_STAT_BCH * 16u; i += 256u) s_acc[i] = 0ull;
+  s_cnt[t] = 0u;      // EPV_STAT_BCH * 8 = 256 entries
+  if (t == 0) s_tail = 0u;
+  const uint32_t my_sel = site < n ? S.sel[site] : 0u;
+  s_sel[t + 1u] = (uint8_t)my_sel;
+  if (t == 0) s_sel[0] = site0 >= 1 ? S.sel[site0 - 1] : (uint8_t)0;
+  if (t == 1) s_sel[257] = site0 + 256u < n ? S.sel[site0 + 256u] : (uint8_t)0;
   __syncthreads();
-  if (threadIdx.x < 16)
-    partial[((uint64_t)blockIdx.x * S.B + b) * 16u + threadIdx.x] =
-        (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+  const uint64_t mbase = (my_sel ? Bn : 0ull) + site;
+  // the two columns next to the block: threads 0 and 1 fetch them
+  const bool edge = (t == 0 && site0 >= 1) || (t == 1 && site0 + 256u < n);
+  const uint64_t esite = t == 0 ? site0 - 1 : site0 + 256u;
+  const uint64_t ebase = (s_sel[t == 0 ? 0 : 257] ? Bn : 0ull) + esite;
+
+  auto merge_item = [&](uint32_t item) __attribute__((always_inline)) {
+    const uint32_t ti = item & 255u, bl = item >> 8, b = b_lo + bl;
+    const uint64_t si = site0 + ti;
+    const PathRef L = path_ref(S, s_sel[ti], b, si - 1), M = path_ref(S, s_sel[ti + 1u], b, si),
+                  R = path_ref(S, s_sel[ti + 2u], b, si + 1);
+    AccExact A;
+    A.acc = s_acc + bl * 16u;
+    A.scale = statscale[b + 1u];
+    merge3(L, M, R, n, S.blen[b + 1u], A);
+  };
+
+  uint32_t head = 0u, buf = 0u;
+  for (uint32_t b = b_lo; b < b_hi; ++b, buf ^= 1u) {
+    const epv_meta_t m = site < n ? S.meta[mbase + (uint64_t)b * n] : (epv_meta_t)0;
+    s_meta[buf][t + 1u] = m;
+    if (t < 2u) s_meta[buf][t == 0 ? 0 : 257] = edge ? S.meta[ebase + (uint64_t)b * n] : (epv_meta_t)0;
+    __syncthreads();
+    const uint32_t ml = s_meta[buf][t], mr = s_meta[buf][t + 2u];
+    const uint32_t or3 = (ml | (uint32_t)m | mr) & EPV_NJ_MASK;
+    const bool fast = on && or3 == 0u, slow = on && or3 != 0u;
+    const unsigned long long mf = __ballot(fast), m2 = __ballot((ml >> EPV_INIT_SHIFT) != 0u),
+                             m1 = __ballot(((uint32_t)m >> EPV_INIT_SHIFT) != 0u), m0 = __ballot((mr >> EPV_INIT_SHIFT) != 0u);
+    if (lane < 8) {
+      const unsigned long long x = mf & ((lane & 4) ? m2 : ~m2) & ((lane & 2) ? m1 : ~m1) & ((lane & 1) ? m0 : ~m0);
+      const uint32_t cnt = (uint32_t)__popcll(x);
+      if (cnt) atomicAdd(&s_cnt[(b - b_lo) * 8u + (uint32_t)lane], cnt);
+    }
+    const unsigned long long ms = __ballot(slow);
+    if (ms) {
+      uint32_t base = 0u;
+      if (lane == 0) base = atomicAdd(&s_tail, (uint32_t)__popcll(ms));
+      base = epv_bcast(base, 0);
+      if (slow) s_ring[(base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull))) & 511u] = t | ((b - b_lo) << 8);
+    }
+    __syncthreads();
+    // s_tail is only written again behind the next iteration's barrier
+    if (s_tail - head >= 256u) {
+      merge_item(s_ring[(head + t) & 511u]);
+      head += 256u;
+    }
+  }
+  __syncthreads();
+  if (t < s_tail - head) merge_item(s_ring[(head + t) & 511u]);
+  __syncthreads();
+  for (uint32_t i = t; i < (b_hi - b_lo) * 16u; i += 256u) {
+    const uint32_t bl = i >> 4, c = i & 15u, b = b_lo + bl;
+    unsigned long long v = s_acc[i];
+    if (c >= 8u) v += (unsigned long long)s_cnt[bl * 8u + (c - 8u)] * epv_stat_fix(S.blen[b + 1u] - 0.0, statscale[b + 1u]);
+    partial[((uint64_t)blockIdx.x * B + b) * 16u + c] = v;
+  }
+}
+
+// Sums of rows of 64-bit integers: out(r, z, c) = the sum of the G consecutive input rows
+// r*G .. r*G+G-1 (rows >= m do not exist; G = 0: all m rows) of column c in slice z.  A block takes 16
+// columns and walks the rows 16 at a time (a wave reads four 128-byte pieces per load).  Integer sums
+// need no fixed order: any chain of such stages (256-site blocks -> rows of 2^g blocks -> all-gather
+// over the GPUs -> total) gives the same bits.
+__global__ __launch_bounds__(256) void epv_isum_kernel(const unsigned long long *in, uint64_t m, uint32_t V, uint64_t G,
+                                                       uint64_t in_row_stride, uint64_t in_z_stride,
+                                                       unsigned long long *out, uint64_t out_row_stride,
+                                                       uint64_t out_z_stride) {
+  __shared__ unsigned long long s_part[16][17];
+  const uint32_t rl = threadIdx.x >> 4, cl = threadIdx.x & 15u;
+  const uint32_t c = blockIdx.x * 16u + cl;
+  const uint64_t r = blockIdx.y, z = blockIdx.z;
+  const uint64_t lo = G ? r * G : 0u;
+  uint64_t hi = G ? lo + G : m;
+  if (hi > m) hi = m;
+  unsigned long long acc = 0ull;
+  if (c < V) {
+    const unsigned long long *p = in + z * in_z_stride + c;
+#pragma unroll 4
+    for (uint64_t i = lo + rl; i < hi; i += 16u) acc += p[i * in_row_stride];
+  }
+  s_part[rl][cl] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16u && c < V) {
+    unsigned long long tot = 0ull;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += s_part[q][threadIdx.x];
+    out[r * out_row_stride + z * out_z_stride + c] = tot;
+  }
 }
 
 // one level of the tree: in[m][V] -> out[ceil(m/256)][V] (V a multiple of 16), each block
@@ -1449,60 +1548,6 @@ __global__ __launch_bounds__(256) void epv_tree_reduce_kernel(const double *in, 
   if (threadIdx.x < 16)
     out[(uint64_t)blockIdx.x * V + g * 16u + threadIdx.x] =
         (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
-}
-
-// Generic piece of the canonical balanced-binary-tree reduction: out(r, z, c) = the balanced
-// pairwise sum of the G consecutive input rows r*G .. r*G+G-1 (rows >= m read as zero) of
-// value column c in slice z.  G is any power of two -- or, with G = 0, "all m rows, zero padded
-// to the next power of two".  One lane per output element runs the binary-counter form of
-// pairwise summation (a stack of at most 40 partial sums): every node of the tree is
-// left + right with aligned power-of-two subtrees, i.e. exactly the sums the 256-ary levels of
-// epv_tree_reduce_kernel and the oracle's recursive tree_sum form, so any chain of such stages
-// (256-site blocks -> rows of 2^g blocks -> all-gather over the GPUs -> total) gives the bits of
-// the one-context reduction.  Consecutive lanes take consecutive columns (coalesced).
-__global__ __launch_bounds__(256) void epv_rowsum_kernel(const double *in, uint64_t m, uint32_t V,
-                                                         uint64_t G, uint64_t in_row_stride,
-                                                         uint64_t in_z_stride, double *out,
-                                                         uint64_t out_row_stride, uint64_t out_z_stride) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= V) return;
-  const uint64_t r = blockIdx.y, z = blockIdx.z;
-  const uint64_t lo = G ? r * G : 0u;
-  uint64_t hi = G ? lo + G : m;
-  if (hi > m) hi = m;
-  const double *p = in + z * in_z_stride + c;
-  double st[40];   // 2^40 rows
-  int sp = 0;
-  for (uint64_t i = lo; i < hi; ++i) {
-    double x = p[i * in_row_stride];
-    for (uint64_t k = i - lo; k & 1u; k >>= 1) x = st[--sp] + x;
-    st[sp++] = x;
-  }
-  // rows beyond m are zeros: a partial subtree plus zeros is the subtree itself, so the stack
-  // collapses from the smallest block upwards (left + right at every node)
-  double x = 0.0;
-  if (sp > 0) {
-    x = st[--sp];
-    while (sp > 0) x = st[--sp] + x;
-  }
-  out[r * out_row_stride + z * out_z_stride + c] = x;
-}
-
-// acc[i] = ((0 + t_0[i]) + t_1[i]) + ... : the same sequence of additions as `batch` calls of
-// the kernel below on a zeroed accumulator
-__global__ void epv_accumulate_seq_kernel(double *acc, const double *tot, uint32_t count, uint64_t batch,
-                                          uint64_t stride) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  double a = 0.0;
-  for (uint64_t w = 0; w < batch; ++w) a += tot[w * stride + i];
-  acc[i] = a;
-}
-
-// acc[i] += one[i]  (J_all_sites += J_one_site, SingleSiteSampler.cpp:582-586)
-__global__ void epv_accumulate_kernel(double *acc, const double *one, uint32_t count) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) acc[i] += one[i];
 }
 
 // =========================================================================

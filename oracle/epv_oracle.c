@@ -27,7 +27,7 @@
  *           Pinned bit-for-bit against the linked reference (oracle/_ref) and
  *           the golden fixtures in tests/golden/.
  *   rung B  parallel-schedule: 3-colour sweep, random-access Philox4x32-10,
- *           orc_exp/orc_log, canonical binary-tree J/D reduction, bounded
+ *           orc_exp/orc_log, exact fixed-point (int64) J/D sums, bounded
  *           jump capacity, and the reference's Nielsen sampler instead of
  *           forward rejection for segments that change state (see
  *           ORC_SAMPLER_* below; pinned against the linked function too).
@@ -56,7 +56,12 @@
 enum { ORC_RNG_MT = 0, ORC_RNG_PHILOX = 1 };
 enum { ORC_MATH_LIBM = 0, ORC_MATH_EPV = 1 };
 enum { ORC_SCHED_SEQ = 0, ORC_SCHED_3COLOUR = 1 };
-enum { ORC_REDUCE_SEQ = 0, ORC_REDUCE_TREE = 1 };
+/* J/D reduction: SEQ = the reference's sequential fp64 sums (ParamEstimation.cpp:92-114);
+ * EXACT = the parallel rung's order-free integers: J as counts, every dwell time as the
+ * fixed-point integer rint(dt * 2^k_b) (k_b per branch, stat_scale_exp below), summed in
+ * int64 -- exactly associative, so the result does not depend on the launch shape, the
+ * number of GPUs or the order atomics land in. */
+enum { ORC_REDUCE_SEQ = 0, ORC_REDUCE_EXACT = 1 };
 /* end-conditioned sampler of a segment whose end state differs from its start state:
  *   FORWARD  plain forward rejection, what the reference's hot path calls
  *            (EndCondSampling.cpp:479-509) -- needs ~1/P(a->b) trials, hundreds to 1e5 on a
@@ -720,18 +725,60 @@ static void site_contrib(const orc_state *st, int b, size_t s, double J[8], doub
   add_suff_stats(PATH(st, b, s - 1), PATH(st, b, s), PATH(st, b, s + 1), st->blen[b], J, D);
 }
 static size_t g_first = 0, g_last = (size_t)-1; /* owned range for the statistics */
-static void tree_sum(const orc_state *st, int b, size_t lo, size_t size, double out[16]) {
-  for (int i = 0; i < 16; ++i) out[i] = 0.0;
-  if (lo >= st->n_sites) return;
-  if (size == 1) {
-    if (lo >= 1 && lo + 1 < st->n_sites && lo >= g_first && lo <= g_last)
-      site_contrib(st, b, lo, out, out + 8);
-    return;
+
+/* ---- exact statistics of the parallel rung.  The dwell times of branch b are summed as
+ * integers q = rint(dt * 2^k_b) with
+ *     k_b = min(61 - e(n_global * T_b), 50 - e(T_b)),   e(x) = the frexp exponent (x < 2^e):
+ * the sum over a whole genome stays below 2^61 and a single term below 2^50 (so that the
+ * device can round with one add of 1.5 * 2^52).  The quantum 2^-k_b is <= 2^-41 of the branch
+ * length at n = 1e6: the total is closer to the exact sum than a sequential fp64 sum.  The
+ * device gets 2^k_b from the host (epv_abi.hip: stat_scale_exp is restated there). */
+static int stat_scale_exp(uint64_t n_global, double T) {
+  if (!(T > 0.0) || !isfinite(T)) return 0;
+  int e_t = 0, e_nt = 0;
+  (void)frexp(T, &e_t);
+  (void)frexp((double)n_global * T, &e_nt);
+  int k = 61 - e_nt;
+  if (50 - e_t < k) k = 50 - e_t;
+  if (k > 1000) k = 1000;
+  if (k < -1000) k = -1000;
+  return k;
+}
+static int64_t stat_fix(double dt, double scale) { return (int64_t)llrint(dt * scale); }
+
+/* Path.cpp:206-301 once more, into integers (same merge and tie rules as add_suff_stats) */
+static void add_suff_stats_exact(const orc_path *l, const orc_path *m, const orc_path *r,
+                                 double tot_time, double scale, int64_t J[8], int64_t D[8]) {
+  int trip = 4 * l->init + 2 * m->init + r->init;
+  double prev = 0.0;
+  uint32_t i = 0, j = 0, k = 0;
+  for (;;) {
+    const double tl = i < l->n ? l->t[i] : INFINITY;
+    const double tm = j < m->n ? m->t[j] : INFINITY;
+    const double tr = k < r->n ? r->t[k] : INFINITY;
+    if (i >= l->n && j >= m->n && k >= r->n) break;
+    if (tl < (tm < tr ? tm : tr)) {
+      D[trip] += stat_fix(tl - prev, scale); prev = tl; trip ^= 4; ++i;
+    } else if (tm < tr) {
+      D[trip] += stat_fix(tm - prev, scale); J[trip] += 1; prev = tm; trip ^= 2; ++j;
+    } else {
+      D[trip] += stat_fix(tr - prev, scale); prev = tr; trip ^= 1; ++k;
+    }
   }
-  double L[16], R[16];
-  tree_sum(st, b, lo, size / 2, L);
-  tree_sum(st, b, lo + size / 2, size / 2, R);
-  for (int i = 0; i < 16; ++i) out[i] = L[i] + R[i];
+  D[trip] += stat_fix(tot_time - prev, scale);
+}
+/* integer sums over the owned interior sites of [lo, lo + count): out[16] = J[8], D[8] */
+static void exact_sum(const orc_state *st, int b, size_t lo, size_t count, int64_t out[16]) {
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  const double scale = ldexp(1.0, stat_scale_exp(st->n_global, st->blen[b]));
+  for (size_t s = lo; s < lo + count && s + 1 < st->n_sites; ++s)
+    if (s >= 1 && s >= g_first && s <= g_last)
+      add_suff_stats_exact(PATH(st, b, s - 1), PATH(st, b, s), PATH(st, b, s + 1), st->blen[b], scale, out, out + 8);
+}
+/* 2^k_b of every node (index 0 unused): what turns the integer D back into time */
+ORC_API void orc_stat_scales(const orc_state *st, double *scale) {
+  scale[0] = 1.0;
+  for (int b = 1; b < st->n_nodes; ++b) scale[b] = ldexp(1.0, stat_scale_exp(st->n_global, st->blen[b]));
 }
 ORC_API void orc_suffstats(const orc_state *st, double *J, double *D) {
   const int B = st->n_nodes - 1;
@@ -741,13 +788,14 @@ ORC_API void orc_suffstats(const orc_state *st, double *J, double *D) {
       if (s >= g_first && s <= g_last)
         for (int b = 1; b <= B; ++b) site_contrib(st, b, s, J + (b - 1) * 8, D + (b - 1) * 8);
   } else {
-    size_t pad = 1;
-    while (pad < st->n_sites) pad *= 2;
     for (int b = 1; b <= B; ++b) {
-      double out[16];
-      tree_sum(st, b, 0, pad, out);
-      memcpy(J + (b - 1) * 8, out, 8 * sizeof(double));
-      memcpy(D + (b - 1) * 8, out + 8, 8 * sizeof(double));
+      int64_t out[16];
+      exact_sum(st, b, 0, st->n_sites, out);
+      const double inv = ldexp(1.0, -stat_scale_exp(st->n_global, st->blen[b]));
+      for (int c = 0; c < 8; ++c) {
+        J[(b - 1) * 8 + c] = (double)out[c];
+        D[(b - 1) * 8 + c] = (double)out[8 + c] * inv;
+      }
     }
   }
 }
@@ -759,18 +807,16 @@ ORC_API void orc_suffstats_range(const orc_state *st, uint64_t first, uint64_t l
   g_first = 0; g_last = (size_t)-1;
 }
 
-/* Rows of the canonical reduction tree, for the tests of the multi-GPU statistics stage: row r
- * is the balanced pairwise sum over the row_sites (a power of two) local sites starting at
- * first_site + r * row_sites, restricted to the owned range [own_first, own_last];
- * out[r][b-1][16] (J then D).  When first_site sits on a multiple of row_sites of the GENOME these
- * are subtrees of the whole-genome tree of orc_suffstats. */
+/* Rows of integer sums, for the tests of the multi-GPU statistics stage: row r covers the
+ * row_sites local sites starting at first_site + r * row_sites, restricted to the owned range
+ * [own_first, own_last]; out[r][b-1][16] int64 (J counts, then fixed-point D). */
 ORC_API void orc_suffstats_rows(const orc_state *st, uint64_t first_site, uint64_t row_sites,
-                                uint64_t n_rows, uint64_t own_first, uint64_t own_last, double *out) {
+                                uint64_t n_rows, uint64_t own_first, uint64_t own_last, int64_t *out) {
   const int B = st->n_nodes - 1;
   g_first = own_first; g_last = own_last;
   for (uint64_t r = 0; r < n_rows; ++r)
     for (int b = 1; b <= B; ++b)
-      tree_sum(st, b, first_site + r * row_sites, row_sites, out + (r * (uint64_t)B + (uint64_t)(b - 1)) * 16);
+      exact_sum(st, b, first_site + r * row_sites, row_sites, out + (r * (uint64_t)B + (uint64_t)(b - 1)) * 16);
   g_first = 0; g_last = (size_t)-1;
 }
 

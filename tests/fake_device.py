@@ -20,17 +20,10 @@ class HostBuf:
         pass
 
 
-def tree_total(rows):
-    """balanced pairwise sum over axis 0, zero padded to a power of two (numpy restatement of
-    the last stage of the device reduction, epv_rowsum_kernel with G = 0)"""
-    m = rows.shape[0]
-    pad = 1
-    while pad < m:
-        pad *= 2
-    cur = np.concatenate([rows, np.zeros((pad - m,) + rows.shape[1:])], axis=0)
-    while cur.shape[0] > 1:
-        cur = cur[0::2] + cur[1::2]
-    return cur[0]
+def rows_total(rows):
+    """integer sum over axis 0 (the statistics are exact int64 sums: any order gives the same
+    bits; numpy restatement of the last stage of the device reduction)"""
+    return rows.sum(axis=0, dtype=np.int64)
 
 
 class OracleDevice:
@@ -177,26 +170,31 @@ class OracleDevice:
         nb = (self.n - self.right + 255) // 256 - self.left // 256
         n_rows = (nb + row_blocks - 1) // row_blocks
         V = self.B * 16
-        rows = rows_buf.np[:n_rows * batch * V * 8].view(np.float64).reshape(n_rows, batch, V)
-        one = np.zeros((n_rows, V))
+        rows = rows_buf.np[:n_rows * batch * V * 8].view(np.int64).reshape(n_rows, batch, V)
+        one = np.zeros((n_rows, V), np.int64)
         nacc = 0
         for i in range(batch):
             nacc += self._sweep(seed, w)
             w += 1
             self.o.L.orc_suffstats_rows(self.o.h, self.left, 256 * row_blocks, n_rows, lo, hi,
-                                        orc._p(one, C.c_double))
+                                        orc._p(one, C.c_int64))
             rows[:, i, :] = one
         return nacc
 
     def reduce_gathered_rows(self, gathered_buf, max_rows, piece_doubles, rows_per_rank, batch, average=True):
         V = self.B * 16
-        g = gathered_buf.np.view(np.float64)
+        g = gathered_buf.np.view(np.int64)
         rows = np.concatenate([g[r * piece_doubles:r * piece_doubles + k * batch * V].reshape(k, batch, V)
                                for r, k in enumerate(rows_per_rank)], axis=0)
-        tot = tree_total(rows)             # [batch][V]
+        tot = rows_total(rows).reshape(batch, self.B, 16)            # [batch][B][16] integers
+        scale = np.zeros(self.B + 1)
+        self.o.L.orc_stat_scales(self.o.h, orc._p(scale, C.c_double))
+        one = tot.astype(np.float64)       # int64 -> double rounds to nearest even, as C does
+        one[:, :, 8:] *= (1.0 / scale[1:])[None, :, None]            # 2^-k: exact
+        one = one.reshape(batch, V)
         acc = np.zeros(V)
         for i in range(batch):             # the sequential accumulation of run_mcmc
-            acc = acc + tot[i]
+            acc = acc + one[i]
         if average:
             acc = acc / float(batch)
         acc = acc.reshape(self.B, 16)

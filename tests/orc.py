@@ -16,7 +16,7 @@ RNG_MT, RNG_PHILOX = 0, 1
 MATH_LIBM, MATH_EPV = 0, 1
 SAMPLER_FORWARD, SAMPLER_NIELSEN = 0, 1
 SCHED_SEQ, SCHED_3COLOUR = 0, 1
-REDUCE_SEQ, REDUCE_TREE = 0, 1
+REDUCE_SEQ, REDUCE_EXACT = 0, 1
 
 dp, u8p, u32p, u64p = (C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32),
                        C.POINTER(C.c_uint64))
@@ -53,7 +53,8 @@ def orc_lib():
         L.orc_mh_site.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
         L.orc_suffstats.argtypes = [C.c_void_p, dp, dp]
         L.orc_suffstats_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, dp, dp]
-        L.orc_suffstats_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, dp]
+        L.orc_suffstats_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64)]
+        L.orc_stat_scales.argtypes = [C.c_void_p, dp]
         L.orc_set_proposal_mode.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_sampler.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_max_qdiff.argtypes = [C.c_void_p]
@@ -220,7 +221,7 @@ class Oracle(_Engine):
         if rung == "A":
             self.L.orc_set_modes(self.h, RNG_MT, MATH_LIBM, SCHED_SEQ, REDUCE_SEQ, 0)
         elif rung == "B":
-            self.L.orc_set_modes(self.h, RNG_PHILOX, MATH_EPV, SCHED_3COLOUR, REDUCE_TREE, cap)
+            self.L.orc_set_modes(self.h, RNG_PHILOX, MATH_EPV, SCHED_3COLOUR, REDUCE_EXACT, cap)
         else:
             self.L.orc_set_modes(self.h, *rung, cap)
         self.rung = rung

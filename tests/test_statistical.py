@@ -65,7 +65,7 @@ def test_parallel_rung_is_insensitive_to_the_exp_log_pair():
     model, tree, fp = simulate("tree", 20000, seed=5)
     outs = []
     for math in (orc.MATH_EPV, orc.MATH_LIBM):
-        o = orc.Oracle(tree, model, fp, (orc.RNG_PHILOX, math, orc.SCHED_3COLOUR, orc.REDUCE_TREE), cap=16, seed=3)
+        o = orc.Oracle(tree, model, fp, (orc.RNG_PHILOX, math, orc.SCHED_3COLOUR, orc.REDUCE_EXACT), cap=16, seed=3)
         o.reset()
         nacc = sum(o.sweep(w) for w in range(3))
         outs.append((nacc, o.paths()))
