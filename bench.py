@@ -12,12 +12,17 @@ Inputs are resident in HBM before the timed region; file IO, upload/download and
 O(8) host M-step are outside it.
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 it is launched by torch.distributed.run (one rank per GPU, RCCL): the genome
-of N * n sites is cut into contiguous shards with wide halos that each rank updates
-redundantly (the RNG is keyed by the global site index), so one step needs exactly two
-exchanges: a halo refresh before reset() and one all-gather of the J/D rows afterwards,
-both on device buffers handed to RCCL as they are (epievo_amd/parallel.py).
-Rank 0 prints ONE JSON line.
+runs the product's C++ EM driver, epv::SingleSiteSampler (epievo_amd/csrc/host/epv_sampler.cpp,
+the class the epievo_* CLIs use) through libepv_driver.so.  The genome of N * n sites is cut into
+contiguous shards with wide halos that each GPU updates redundantly (the RNG is keyed by the
+global site index), so one step needs exactly two exchanges over RCCL (libepv_rccl.so): a halo
+refresh before reset() and one all-gather of the integer J/D rows afterwards, both on device
+buffers.  Called plainly, one process drives all N GPUs (ncclCommInitAll; EPV_DEVICES=0,0,0,0
+rehearses four slots on one GPU through the loopback transport); under
+`python -m torch.distributed.run --nproc-per-node N` every rank drives its GPU and joins the
+communicator with ncclCommInitRank (torch.distributed/gloo only carries the id, the barriers and
+the max over ranks).  N = 1: n = 1e6 (BASELINE config 3, the metric's); N > 1: 1.25e6 per GPU,
+i.e. BASELINE config 4's n = 1e7 at N = 8.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -120,33 +125,147 @@ def cpu_baseline(model, tree, fp, budget_s=20.0):
     return out
 
 
+class CppEngine:
+    """the product's C++ EM driver (epv::SingleSiteSampler through libepv_driver.so): every GPU of
+    the run in this process (ncclCommInitAll), or -- under torch.distributed.run -- this rank's GPU
+    with the communicator made by ncclCommInitRank from an id rank 0 broadcasts"""
+
+    def __init__(self, args, model, tree, world, rank, local_rank, dist):
+        from epievo_amd import driver, host
+        self.world, self.rank = world, rank
+        cap = 16 if args.config != "pair" else 0
+        if dist is None:
+            # plain launch: --gpus N devices, or the list of EPV_DEVICES (repeats rehearse N GPUs on fewer)
+            env = os.environ.get("EPV_DEVICES")
+            devices = [int(x) for x in env.split(",")] if env else list(range(args.gpus))
+            self.n_gpus = len(devices)
+            self.n_global = args.sites * self.n_gpus
+            self.s = driver.CppSampler(BURN_IN, BATCH, devices=devices, capacity=cap)
+            self.fp = host.simulate(model, tree, self.n_global, SEED)
+            self.s.reset(model, tree, self.fp)
+            self.fp_sample = self.fp
+        else:
+            self.n_gpus = world
+            self.n_global = args.sites * world
+            ident = [driver.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            cuts = driver.shard_cuts(self.n_global, world, BURN_IN, BATCH)
+            if len(cuts) - 1 != world:
+                sys.exit("a genome of %d sites cannot feed %d GPUs" % (self.n_global, world))
+            self.s = driver.CppSampler(BURN_IN, BATCH, capacity=cap or 32, rank=(local_rank, world, rank, ident[0]))
+            # every rank simulates its own columns; the halos arrive from the neighbours before the first reset
+            self.fp_sample = host.simulate(model, tree, cuts[rank + 1] - cuts[rank], SEED + rank)
+            self.s.reset(model, tree, self.fp_sample, n_global=self.n_global)
+        self.model = model
+        self.lay = self.s.layout()
+        self.k_eff = max(1, self.lay["parts_here"] // max(1, self.lay["slots_here"]))
+        self.transport = ("rccl" if self.lay["rccl"] else "loopback") if self.n_gpus > 1 else "none (one GPU)"
+        self.halo = self.lay["halo"]
+        self.owned_per_gpu = self.n_global / float(self.n_gpus)
+
+    def step(self, i):
+        self.s.reset(self.model)
+        return self.s.run_mcmc(SEED, i)
+
+    def set_timing(self, every):
+        self.s.set_timing(every)
+
+    def kernel_time_ms(self):
+        return self.s.kernel_time_ms()
+
+    def set_options(self, **kw):
+        self.s.set_options(**kw)
+
+    def phase_mode(self):
+        return self.s.phase_mode()
+
+    def describe(self):
+        return "C++ epv::SingleSiteSampler (epv_sampler.cpp + libepv_rccl.so); " + self.lay["text"]
+
+
+class TorchEngine:
+    """the Python one-process-per-GPU driver (epievo_amd/parallel.py over torch.distributed): the same
+    C-ABI primitives, kept for A/B runs against the C++ driver (--driver torch)"""
+
+    def __init__(self, args, model, tree, world, rank, local_rank, dist, torch):
+        from epievo_amd import host
+        from epievo_amd.parallel import ShardedSampler, TorchComm, NullComm, LocalGroup, shard_cuts
+        comm = TorchComm(dist, torch.device("cuda", local_rank)) if dist is not None else NullComm()
+        self.n_gpus = world
+        self.n_global = args.sites * world
+        cuts = shard_cuts(self.n_global, world)
+        self.fp_sample = host.simulate(model, tree, cuts[rank + 1] - cuts[rank], SEED + rank)
+        k_local = args.shards_per_gpu if args.shards_per_gpu > 0 else (3 if tree.n_nodes - 1 <= 8 else 2)
+        self.ss = ShardedSampler(comm, device=local_rank,
+                                 device_factory=(lambda dev: LocalGroup(dev, k_local, BURN_IN + BATCH)) if k_local > 1 else None)
+        self.ss.setup(model, tree, self.fp_sample, cuts, capacity=16 if args.config != "pair" else 0,
+                      sweeps_per_refresh=BURN_IN + BATCH)
+        self.ss.dev.set_timing(False)
+        self.k_eff = len(self.ss.dev.subs) if hasattr(self.ss.dev, "subs") else 1
+        self.transport = ("rccl" if args.backend == "nccl" else "gloo (host bounce)") if world > 1 else "none (one GPU)"
+        self.halo = self.ss.halo
+        self.owned_per_gpu = float(self.ss.owned_sites())
+
+    def step(self, i):
+        self.ss.reset()
+        return self.ss.run_mcmc(BURN_IN, BATCH, SEED, sweep_base=i * (BURN_IN + BATCH))
+
+    def set_timing(self, every):
+        self.ss.dev.set_timing(every)
+
+    def kernel_time_ms(self):
+        return self.ss.dev.kernel_time_ms()
+
+    def set_options(self, **kw):
+        self.ss.dev.set_options(**kw)
+
+    def phase_mode(self):
+        return self.ss.dev.phase_mode()
+
+    def describe(self):
+        return "Python driver (epievo_amd/parallel.py over torch.distributed)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--sites", type=int, default=N_SITES, help="sites per GPU")
+    ap.add_argument("--sites", type=int, default=0,
+                    help="sites per GPU; 0 = 1e6 on one GPU (BASELINE config 3, the metric's), 1.25e6 per GPU on "
+                         "several (8 GPUs = BASELINE config 4's n = 1e7)")
     ap.add_argument("--config", default="tree", choices=["tree", "pair", "bal16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-leg", action="store_true",
                     help="skip the extra steps in reference-arithmetic mode (profiling runs)")
+    ap.add_argument("--driver", default="cpp", choices=["cpp", "torch"],
+                    help="cpp: the product's C++ EM driver epv::SingleSiteSampler (what the epievo_* CLIs run), every "
+                         "GPU in this process when launched plainly, one rank per GPU under torch.distributed.run; "
+                         "torch: the Python driver over torch.distributed (A/B)")
     ap.add_argument("--shards-per-gpu", type=int, default=0,
-                    help="contexts per GPU (epievo_amd.parallel.LocalGroup): their launches fill each "
-                         "other's tails; results are bit-identical to 1.  0 = by tree size: 3 on small "
-                         "trees (fused colour phase), 2 on large ones")
+                    help="contexts per GPU: their launches fill each other's tails; results are bit-identical "
+                         "to 1.  0 = by tree size: 3 on small trees (fused colour phase), 2 on large ones")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL) is the product path; gloo lets several ranks share one "
-                         "GPU to rehearse the N>1 code path on a 1-GPU box")
+                    help="--driver torch only: nccl (= RCCL) or gloo (lets several ranks share one GPU to "
+                         "rehearse the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py "
-                     "--gpus %d ..." % (args.gpus, args.gpus))
+    launched = world > 1 or (os.environ.get("EPV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if launched:
         args.gpus = world
+    elif args.gpus > 1 and args.driver == "torch":
+        sys.exit("--driver torch needs: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                 % (args.gpus, args.gpus))
+    if args.shards_per_gpu > 0:
+        os.environ["EPV_CONTEXTS_PER_GPU"] = str(args.shards_per_gpu)    # the C++ driver reads it
+    n_gpus_nominal = args.gpus
+    if not launched and os.environ.get("EPV_DEVICES"):
+        n_gpus_nominal = len(os.environ["EPV_DEVICES"].split(","))
+    if args.sites <= 0:
+        args.sites = N_SITES if n_gpus_nominal == 1 else 1250000
 
     # stdout carries exactly one JSON line (rank 0).  Libraries print there too (RCCL's version
     # banner, gloo's connection notes): send everything else written to fd 1 to stderr and
@@ -156,75 +275,61 @@ def main():
     os.dup2(2, 1)
 
     import torch
-    from epievo_amd import host
-    from epievo_amd.parallel import ShardedSampler, TorchComm, NullComm, LocalGroup, shard_cuts
     from epievo_amd.workloads import ref_test_model, config
 
     dist = None
-    # EPV_BENCH_FORCE_DIST=1 under torchrun with one rank exercises the RCCL set-up and the
-    # barrier / all-reduce legs on a 1-GPU box (the shard exchange itself needs >= 2 GPUs)
-    if world > 1 or (os.environ.get("EPV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ):
+    if launched:
         import torch.distributed as dist
-        if args.backend == "nccl":
+        if args.driver == "cpp":
+            # control plane only (the id broadcast, barriers, the max over ranks): the data plane is
+            # RCCL inside libepv_rccl.so, through the communicator the C++ driver makes
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        elif args.backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            comm = TorchComm(dist, torch.device("cuda", local_rank))
         else:
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
-            # the buffers stay on the GPU; gloo cannot move them, TorchComm bounces them through the host
-            comm = TorchComm(dist, torch.device("cuda", local_rank))
-    else:
-        comm = NullComm()
 
     model = ref_test_model()
     tree = config(args.config)
-    n_local = args.sites
-    n_global = n_local * world
-    # contiguous shards cut on whole rows of the statistics tree (16384 sites): n_local sites per
-    # GPU on average, at most one row more or less on any one
-    cuts = shard_cuts(n_global, world)
-    n_own = cuts[rank + 1] - cuts[rank]
-    # every rank simulates its own shard (+ halos come from the neighbours' edges)
-    fp_own = host.simulate(model, tree, n_own, SEED + rank)
-    kbar = len(fp_own.jumps) / float(n_own * (tree.n_nodes - 1))
-
-    k_local = args.shards_per_gpu if args.shards_per_gpu > 0 else (3 if tree.n_nodes - 1 <= 8 else 2)
-    ss = ShardedSampler(comm, device=local_rank,
-                        device_factory=(lambda dev: LocalGroup(dev, k_local, BURN_IN + BATCH)) if k_local > 1 else None)
-    # 16 jump slots per (site, branch) on the short trees; the T = 1 branch picks its own
-    ss.setup(model, tree, fp_own, cuts, capacity=16 if args.config != "pair" else 0,
-             sweeps_per_refresh=BURN_IN + BATCH)
-    ss.dev.set_timing(False)
+    if args.driver == "cpp":
+        eng = CppEngine(args, model, tree, world, rank, local_rank, dist)
+    else:
+        eng = TorchEngine(args, model, tree, world, rank, local_rank, dist, torch)
+    n_gpus, n_global, n_local = eng.n_gpus, eng.n_global, args.sites
+    fp_own = eng.fp_sample
+    kbar = len(fp_own.jumps) / float(fp_own.n_sites * (tree.n_nodes - 1))
 
     def barrier():
+        for d in range(torch.cuda.device_count() if dist is None else 0):
+            torch.cuda.synchronize(d)            # plain launch: this process drives every GPU
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(i):
-        ss.reset()
-        return ss.run_mcmc(BURN_IN, BATCH, SEED, sweep_base=i * (BURN_IN + BATCH))
-
+    step = eng.step
     for i in range(args.warmup):
         step(i)
     barrier()
-    ss.dev.kernel_time_ms()          # clear the timing accumulators
-    ss.dev.set_timing(TIMING_EVERY)  # HIP events around every TIMING_EVERY-th colour-phase launch of each context
+    eng.kernel_time_ms()          # clear the timing accumulators
+    eng.set_timing(TIMING_EVERY)  # HIP events around every TIMING_EVERY-th colour-phase launch of each context
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
     el = time.perf_counter() - t0
-    ss.dev.set_timing(False)
-    avg_ms, n_launch = ss.dev.kernel_time_ms()
+    eng.set_timing(0)
+    avg_ms, n_launch = eng.kernel_time_ms()
 
     def rank_max(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        on_gpu = args.driver == "torch" and args.backend == "nccl"
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -235,7 +340,7 @@ def main():
     # the headline so that the cost of that arithmetic -- which changes no path -- is on record
     k_ref, el_ref = 0, 0.0
     if not args.no_reference_leg:
-        ss.dev.set_options(reference_proposal_ratio=True)
+        eng.set_options(reference_proposal_ratio=True)
         k_ref = max(1, min(2, args.steps))
         step(args.warmup + args.steps)
         barrier()
@@ -244,7 +349,7 @@ def main():
             step(args.warmup + args.steps + 1 + i)
         barrier()
         el_ref = rank_max(time.perf_counter() - t0)
-        ss.dev.set_options()
+        eng.set_options()
 
     B = tree.n_nodes - 1
     owned_total = n_global - 2
@@ -253,15 +358,21 @@ def main():
 
     if rank == 0:
         bytes_per = algorithmic_bytes_per_resample(kbar, B)
-        k_eff = len(ss.dev.subs) if hasattr(ss.dev, "subs") else 1
-        # a timed launch covers one colour phase of ONE of the k_eff shards of this GPU
-        per_launch_units = ss.owned_sites() / 3.0 * B / k_eff
+        k_eff = eng.k_eff
+        # a timed launch covers one colour phase of ONE of the k_eff contexts of a GPU
+        per_launch_units = eng.owned_per_gpu / 3.0 * B / k_eff
         achieved = per_launch_units * bytes_per / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(args.config, {}).get("hbm_bytes_per_launch")
+                tq = json.load(open(tj)).get(args.config, {})
+                traffic = tq.get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    # a citation, not this run's counters: PMC passes cannot run next to the timed region
+                    traffic_source = ("profiles/%s_pmc_hbm_%s.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                      "passes, one context per GPU; committed file, not measured in this run)"
+                                      % (tq.get("round", "?"), args.config))
             except Exception:
                 traffic = None
         # what really bounds these kernels: VALU issue.  Instruction counts per launch come from
@@ -282,49 +393,59 @@ def main():
                              "measured_ms_per_launch": avg_ms, "concurrent_launches": k_eff,
                              # k_eff launches share the SIMDs: the device issues k_eff * insts in avg_ms
                              "frac": k_eff * bound_ms / avg_ms, "lane_utilisation": q.get("lane_utilisation"),
-                             "source": "profiles/%s_pmc_valu_%s.csv" % (q["round"], args.config)}
+                             "source": "profiles/%s_pmc_valu_%s.csv" % (q["round"], args.config),
+                             "profiled_phase_mode": q.get("phase_mode")}
             except Exception:
                 issue = None
         achieved_device = achieved * k_eff
         from epievo_amd.sampler import DeviceSampler
-        phase_mode = ss.dev.phase_mode()
+        phase_mode = eng.phase_mode()
         phase_kernels = DeviceSampler.PHASE_KERNELS[phase_mode]
-        if issue is not None:
-            issue["profiled_phase_mode"] = q.get("phase_mode")
+        if args.config == "tree":
+            if n_gpus == 1:
+                workload = ("tree.nwk (4 branches), n=%d sites per GPU, one step = reset + run_mcmc(-L %d -B %d) as "
+                            "epievo_est_params_histories drives it" % (n_local, BURN_IN, BATCH))
+            else:
+                workload = ("tree.nwk (4 branches), n=%d sites over %d GPUs (%d per GPU; 8 GPUs = BASELINE config 4's "
+                            "n = 1e7), one step = reset + run_mcmc(-L %d -B %d) as epievo_est_params_histories -g all "
+                            "drives it" % (n_global, n_gpus, n_local, BURN_IN, BATCH))
+        else:
+            workload = "%s, n=%d per GPU" % (args.config, n_local)
         out = {
             "metric": "site-branch path resamples/sec at n=1e6, 4-leaf tree",
-            "value": value, "unit": "site-branch resamples/s", "n_gpus": world,
+            "value": value, "unit": "site-branch resamples/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "tree.nwk (4 branches), n=%d sites per GPU, one step = "
-                                   "reset + run_mcmc(-L %d -B %d) as epievo_est_params_histories "
-                                   "drives it" % (n_local, BURN_IN, BATCH) if args.config == "tree"
-                       else "%s, n=%d per GPU" % (args.config, n_local),
-                       "sites_per_gpu": n_local, "branches": B, "burn_in": BURN_IN, "batch": BATCH,
-                       "mean_jumps_per_path": kbar, "shards_per_gpu": k_eff,
-                       "sharding": "contiguous site shards cut on 16384-site rows of the statistics tree, "
-                                   "%d-column redundant halos refreshed once per step, "
-                                   "%d GPU shard(s) x %d concurrent context(s) per GPU" % (ss.halo, world, k_eff)},
+            "config": {"workload": workload, "sites_per_gpu": n_local, "sites_total": n_global, "branches": B,
+                       "burn_in": BURN_IN, "batch": BATCH, "mean_jumps_per_path": kbar, "shards_per_gpu": k_eff,
+                       "driver": eng.describe(), "transport": eng.transport,
+                       "launch": ("torch.distributed.run, one rank per GPU" if dist is not None
+                                  else "one process drives every GPU"),
+                       "sharding": "contiguous site shards cut on 16384-site rows, %d-column redundant halos "
+                                   "refreshed once per step, one all-gather of integer J/D rows per step; "
+                                   "%d GPU shard(s) x %d concurrent context(s) per GPU" % (eng.halo, n_gpus, k_eff)},
             # frac = what the DEVICE sustains: k_eff launches (one per context of this GPU) run
             # concurrently, each timed with its own HIP events on its own stream
             "roofline": {"bound": "hbm", "kernel": phase_kernels + " (one colour phase of one context = one timed launch group)",
                          "achieved": achieved_device,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_device / HBM_PEAK_GBS,
-                         "traffic": traffic, "bytes_per_resample": bytes_per,
+                         "traffic": traffic, "traffic_source": traffic_source, "bytes_per_resample": bytes_per,
                          "resamples_per_launch": per_launch_units, "avg_launch_ms": avg_ms,
                          "launches_timed": n_launch, "concurrent_launches": k_eff,
                          "achieved_per_launch": achieved, "phase_mode": phase_mode, "issue": issue},
         }
-        out["config"]["proposal_ratio"] = ("exact (q(old)/q(new) = 1 when the root state is kept: "
-                                           "DESIGN.md section 4.1); same paths as the reference's sums")
+        out["config"]["proposal_ratio"] = (
+            "exact: with the root state kept, log q(old) - log q(new) telescopes to 0 (DESIGN.md section 2), so the "
+            "sums are skipped; the chain equals the one with the reference's sums unless a rounding difference of "
+            "~1e-12 flips an accept decision (probability ~1e-3 per full run)")
         if k_ref:
-          out["reference_proposal_arithmetic"] = {
-              "value": float(k_ref) * (BURN_IN + BATCH) * owned_total * B / el_ref, "unit": "site-branch resamples/s",
-              "ms_per_step": el_ref / k_ref * 1e3, "steps": k_ref,
-              "note": "EPV_OPT_REFERENCE_PROPOSAL_RATIO: the two log-probability sums of "
-                      "SingleSiteSampler.cpp:180-339 evaluated as the reference does"}
-        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
+            out["reference_proposal_arithmetic"] = {
+                "value": float(k_ref) * (BURN_IN + BATCH) * owned_total * B / el_ref, "unit": "site-branch resamples/s",
+                "ms_per_step": el_ref / k_ref * 1e3, "steps": k_ref,
+                "note": "EPV_OPT_REFERENCE_PROPOSAL_RATIO: the two log-probability sums of "
+                        "SingleSiteSampler.cpp:180-339 evaluated as the reference does"}
+        if not args.no_cpu_baseline and n_gpus == 1:   # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(model, tree, fp_own)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)

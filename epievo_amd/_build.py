@@ -6,6 +6,9 @@
                  (the C-ABI of include/epievo_mi355x_comm.h: halo exchange + statistics all-gather)
   build_host()   g++                          -> epievo_amd/libepv_host.so
                  (model / M-step / file formats / synthetic-input simulator)
+  build_driver() g++                          -> epievo_amd/libepv_driver.so
+                 (the C-ABI of include/epievo_mi355x_driver.h: epv::SingleSiteSampler, the C++ EM
+                 driver of the CLIs, for bench.py and the tests; links the two libraries above)
   build_cli()    g++                          -> epievo_amd/bin/epievo_*  (drop-in CLIs)
   build_oracle() make -C oracle [ref]         -> oracle/liborc.so (+ oracle/_ref/…)
                  TEST INFRASTRUCTURE ONLY; the product never loads it.
@@ -23,6 +26,7 @@ INCLUDE = os.path.join(ROOT, "include")
 HIP_SO = os.path.join(PKG, "libepievo_mi355x.so")
 COMM_SO = os.path.join(PKG, "libepv_rccl.so")
 HOST_SO = os.path.join(PKG, "libepv_host.so")
+DRIVER_SO = os.path.join(PKG, "libepv_driver.so")
 BIN_DIR = os.path.join(PKG, "bin")
 
 HOST_SOURCES = ["epv_model.cpp", "epv_sim.cpp", "epv_io.cpp", "epv_indep.cpp", "epv_forward.cpp", "epv_host_abi.cpp"]
@@ -89,6 +93,16 @@ def build_host(force=False):
     return HOST_SO
 
 
+def build_driver(force=False):
+    srcs = [os.path.join(HOST, f) for f in ("epv_driver_abi.cpp", "epv_sampler.cpp")]
+    deps = srcs + [os.path.join(HOST, "epv_sampler.hpp"), os.path.join(INCLUDE, "epievo_mi355x_driver.h"), HIP_SO, COMM_SO]
+    if not force and _newer(DRIVER_SO, deps):
+        return DRIVER_SO
+    _run(["g++"] + HOST_FLAGS + ["-shared", "-I", HOST, "-I", INCLUDE, "-o", DRIVER_SO] + srcs +
+         ["-L", PKG, "-lepievo_mi355x", "-lepv_rccl", "-Wl,-rpath,$ORIGIN"])
+    return DRIVER_SO
+
+
 def build_oracle(with_ref=True):
     odir = os.path.join(ROOT, "oracle")
     _run(["make", "-C", odir])
@@ -101,6 +115,7 @@ def build_all(force=False):
     build_host(force)
     build_hip(force)
     build_comm(force)
+    build_driver(force)
     cli = os.path.join(HOST, "cli")
     if os.path.isdir(cli):
         build_cli(force)

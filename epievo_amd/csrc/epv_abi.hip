@@ -791,6 +791,9 @@ static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base);
 
 EPV_API int epv_set_options(epv_ctx *c, uint32_t flags) {
   if (!c) return EPV_ERR_ARG;
+  if (flags & EPV_OPT_SAMPLE_ROOT)
+    return fail(c, EPV_ERR_ARG, "EPV_OPT_SAMPLE_ROOT (SingleSiteSampler::SAMPLE_ROOT = true) is not supported: "
+                                "the kernels keep the root state, as every program of the reference does");
   if (flags & ~(uint32_t)(EPV_OPT_REFERENCE_PROPOSAL_RATIO | EPV_OPT_FORWARD_REJECTION))
     return fail(c, EPV_ERR_ARG, "unknown option bits");
   static_assert(EPV_OPT_REFERENCE_PROPOSAL_RATIO == EPV_FLAG_REFERENCE_PROPOSAL_RATIO &&

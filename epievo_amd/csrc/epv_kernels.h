@@ -1417,35 +1417,42 @@ __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t fi
   __shared__ uint32_t s_cnt[EPV_STAT_BCH * 8u];     // triples without a jump, per (branch, context)
   __shared__ epv_meta_t s_meta[2][258];
   __shared__ uint8_t s_sel[258];
-  __shared__ uint32_t s_ring[512];                  // thread | local branch << 8
+  // queue of the pairs that need a merge: thread | local branch << 8, and the triple's three meta words
+  __shared__ uint32_t s_ring[512], s_ring_lm[512];
+  __shared__ epv_meta_t s_ring_r[512];
   __shared__ uint32_t s_tail;
   const uint32_t t = threadIdx.x;
   const int lane = epv_lane();
   const uint32_t B = S.B;
   const uint32_t b_lo = blockIdx.y * EPV_STAT_BCH, b_hi = (b_lo + EPV_STAT_BCH < B) ? b_lo + EPV_STAT_BCH : B;
-  const uint64_t n = S.n, Bn = (uint64_t)B * n;
+  const uint64_t n = S.n, Bn = (uint64_t)B * n, Cn = (uint64_t)S.C * n;
   // block0: first 256-site block to process (partial[] is relative to it)
   const uint64_t site0 = (block0 + blockIdx.x) * 256u, site = site0 + t;
   const bool on = site >= first && site <= last && site >= 1 && site + 1 < n;
-  for (uint32_t i = t; i < EPV_STAT_BCH * 16u; i += 256u) s_acc[i] = 0ull;
-  s_cnt[t] = 0u;      // EPV_STAT_BCH * 8 = 256 entries
-  if (t == 0) s_tail = 0u;
+  // the kernel is a chain of memory round trips (sel -> meta -> jumps), not of instructions: every
+  // load that does not depend on another is issued with its siblings
   const uint32_t my_sel = site < n ? S.sel[site] : 0u;
-  s_sel[t + 1u] = (uint8_t)my_sel;
-  if (t == 0) s_sel[0] = site0 >= 1 ? S.sel[site0 - 1] : (uint8_t)0;
-  if (t == 1) s_sel[257] = site0 + 256u < n ? S.sel[site0 + 256u] : (uint8_t)0;
-  __syncthreads();
-  const uint64_t mbase = (my_sel ? Bn : 0ull) + site;
   // the two columns next to the block: threads 0 and 1 fetch them
   const bool edge = (t == 0 && site0 >= 1) || (t == 1 && site0 + 256u < n);
   const uint64_t esite = t == 0 ? site0 - 1 : site0 + 256u;
-  const uint64_t ebase = (s_sel[t == 0 ? 0 : 257] ? Bn : 0ull) + esite;
+  const uint32_t e_sel = edge ? S.sel[esite] : 0u;
+  for (uint32_t i = t; i < EPV_STAT_BCH * 16u; i += 256u) s_acc[i] = 0ull;
+  s_cnt[t] = 0u;      // EPV_STAT_BCH * 8 = 256 entries
+  if (t == 0) s_tail = 0u;
+  s_sel[t + 1u] = (uint8_t)my_sel;
+  if (t < 2u) s_sel[t == 0 ? 0 : 257] = (uint8_t)e_sel;
+  const uint64_t mbase = (my_sel ? Bn : 0ull) + site;
+  const uint64_t ebase = (e_sel ? Bn : 0ull) + esite;
 
-  auto merge_item = [&](uint32_t item) __attribute__((always_inline)) {
+  auto merge_item = [&](uint32_t slot) __attribute__((always_inline)) {
+    const uint32_t item = s_ring[slot], lm = s_ring_lm[slot], mr = s_ring_r[slot];
     const uint32_t ti = item & 255u, bl = item >> 8, b = b_lo + bl;
     const uint64_t si = site0 + ti;
-    const PathRef L = path_ref(S, s_sel[ti], b, si - 1), M = path_ref(S, s_sel[ti + 1u], b, si),
-                  R = path_ref(S, s_sel[ti + 2u], b, si + 1);
+    const uint32_t ml = lm & 0xffffu, mm = lm >> 16;
+    PathRef L, M, R;
+    L.j = S.jumps + (s_sel[ti] ? Bn * S.C : 0ull) + (uint64_t)b * Cn + (si - 1); L.nj = ml & EPV_NJ_MASK; L.init = ml >> EPV_INIT_SHIFT;
+    M.j = S.jumps + (s_sel[ti + 1u] ? Bn * S.C : 0ull) + (uint64_t)b * Cn + si; M.nj = mm & EPV_NJ_MASK; M.init = mm >> EPV_INIT_SHIFT;
+    R.j = S.jumps + (s_sel[ti + 2u] ? Bn * S.C : 0ull) + (uint64_t)b * Cn + (si + 1); R.nj = mr & EPV_NJ_MASK; R.init = mr >> EPV_INIT_SHIFT;
     AccExact A;
     A.acc = s_acc + bl * 16u;
     A.scale = statscale[b + 1u];
@@ -1453,37 +1460,56 @@ __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t fi
   };
 
   uint32_t head = 0u, buf = 0u;
-  for (uint32_t b = b_lo; b < b_hi; ++b, buf ^= 1u) {
-    const epv_meta_t m = site < n ? S.meta[mbase + (uint64_t)b * n] : (epv_meta_t)0;
-    s_meta[buf][t + 1u] = m;
-    if (t < 2u) s_meta[buf][t == 0 ? 0 : 257] = edge ? S.meta[ebase + (uint64_t)b * n] : (epv_meta_t)0;
-    __syncthreads();
-    const uint32_t ml = s_meta[buf][t], mr = s_meta[buf][t + 2u];
-    const uint32_t or3 = (ml | (uint32_t)m | mr) & EPV_NJ_MASK;
-    const bool fast = on && or3 == 0u, slow = on && or3 != 0u;
-    const unsigned long long mf = __ballot(fast), m2 = __ballot((ml >> EPV_INIT_SHIFT) != 0u),
-                             m1 = __ballot(((uint32_t)m >> EPV_INIT_SHIFT) != 0u), m0 = __ballot((mr >> EPV_INIT_SHIFT) != 0u);
-    if (lane < 8) {
-      const unsigned long long x = mf & ((lane & 4) ? m2 : ~m2) & ((lane & 2) ? m1 : ~m1) & ((lane & 1) ? m0 : ~m0);
-      const uint32_t cnt = (uint32_t)__popcll(x);
-      if (cnt) atomicAdd(&s_cnt[(b - b_lo) * 8u + (uint32_t)lane], cnt);
+  constexpr uint32_t GB = 4u;      // branches whose meta words are fetched together
+  for (uint32_t b0 = b_lo; b0 < b_hi; b0 += GB) {
+    epv_meta_t mq[GB], eq[GB];
+#pragma unroll
+    for (uint32_t q = 0; q < GB; ++q) {
+      const bool have = b0 + q < b_hi;
+      mq[q] = (have && site < n) ? S.meta[mbase + (uint64_t)(b0 + q) * n] : (epv_meta_t)0;
+      eq[q] = (have && edge) ? S.meta[ebase + (uint64_t)(b0 + q) * n] : (epv_meta_t)0;
     }
-    const unsigned long long ms = __ballot(slow);
-    if (ms) {
-      uint32_t base = 0u;
-      if (lane == 0) base = atomicAdd(&s_tail, (uint32_t)__popcll(ms));
-      base = epv_bcast(base, 0);
-      if (slow) s_ring[(base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull))) & 511u] = t | ((b - b_lo) << 8);
-    }
-    __syncthreads();
-    // s_tail is only written again behind the next iteration's barrier
-    if (s_tail - head >= 256u) {
-      merge_item(s_ring[(head + t) & 511u]);
-      head += 256u;
+#pragma unroll
+    for (uint32_t q = 0; q < GB; ++q) {
+      const uint32_t b = b0 + q;
+      if (b >= b_hi) break;
+      const uint32_t m = mq[q];
+      s_meta[buf][t + 1u] = (epv_meta_t)m;
+      if (t < 2u) s_meta[buf][t == 0 ? 0 : 257] = eq[q];
+      __syncthreads();
+      const uint32_t ml = s_meta[buf][t], mr = s_meta[buf][t + 2u];
+      const uint32_t or3 = (ml | m | mr) & EPV_NJ_MASK;
+      const bool fast = on && or3 == 0u, slow = on && or3 != 0u;
+      const unsigned long long mf = __ballot(fast), m2 = __ballot((ml >> EPV_INIT_SHIFT) != 0u),
+                               m1 = __ballot((m >> EPV_INIT_SHIFT) != 0u), m0 = __ballot((mr >> EPV_INIT_SHIFT) != 0u);
+      if (lane < 8) {
+        const unsigned long long x = mf & ((lane & 4) ? m2 : ~m2) & ((lane & 2) ? m1 : ~m1) & ((lane & 1) ? m0 : ~m0);
+        const uint32_t cnt = (uint32_t)__popcll(x);
+        if (cnt) atomicAdd(&s_cnt[(b - b_lo) * 8u + (uint32_t)lane], cnt);
+      }
+      const unsigned long long ms = __ballot(slow);
+      if (ms) {
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(&s_tail, (uint32_t)__popcll(ms));
+        base = epv_bcast(base, 0);
+        if (slow) {
+          const uint32_t slot = (base + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull))) & 511u;
+          s_ring[slot] = t | ((b - b_lo) << 8);
+          s_ring_lm[slot] = ml | (m << 16);
+          s_ring_r[slot] = (epv_meta_t)mr;
+        }
+      }
+      __syncthreads();
+      // s_tail is only written again behind the next iteration's barrier
+      if (s_tail - head >= 256u) {
+        merge_item((head + t) & 511u);
+        head += 256u;
+      }
+      buf ^= 1u;
     }
   }
   __syncthreads();
-  if (t < s_tail - head) merge_item(s_ring[(head + t) & 511u]);
+  if (t < s_tail - head) merge_item((head + t) & 511u);
   __syncthreads();
   for (uint32_t i = t; i < (b_hi - b_lo) * 16u; i += 256u) {
     const uint32_t bl = i >> 4, c = i & 15u, b = b_lo + bl;

@@ -14,6 +14,7 @@
 #include <random>
 #include <stdexcept>
 #include <chrono>
+#include <cmath>
 #include <thread>
 
 #include "epv_io.hpp"
@@ -99,13 +100,16 @@ int main(int argc, const char **argv) {
     // device keeps one length per branch, hence the same rescaling is applied at load time.
     for (int b = 1; b < th.n_nodes(); ++b)
       if (tot_times[b] != th.branches[b]) {
+        if (!(tot_times[b] > 0.0) || !std::isfinite(tot_times[b]))
+          throw std::runtime_error("paths of node " + th.node_names[b] + ": tot_time must be positive and finite");
         const double scale = th.branches[b] / tot_times[b];
         const uint64_t n = paths.n_sites;
         for (uint64_t k = paths.offsets[(uint64_t)(b - 1) * n]; k < paths.offsets[(uint64_t)b * n]; ++k)
           paths.jumps[k] *= scale;
-        if (VERBOSE)
-          cerr << "[RESCALING PATHS OF NODE " << th.node_names[b] << ": tot_time " << tot_times[b]
-               << " -> branch length " << th.branches[b] << "]" << endl;
+        // always reported: first-iteration statistics of such an input differ from the reference's,
+        // which keeps the file's tot_time until scale_jump_times ("tot_time")
+        cerr << "[RESCALING PATHS OF NODE " << th.node_names[b] << ": tot_time " << tot_times[b]
+             << " -> branch length " << th.branches[b] << "]" << endl;
       }
 
     if (rng_seed == std::numeric_limits<size_t>::max()) {
@@ -123,13 +127,16 @@ int main(int argc, const char **argv) {
     // writing 111 MB (n = 1e6, tree.nwk) takes longer than the E-step of the next iteration, and
     // that E-step needs only the device-resident paths: the file of iteration i is written by a
     // background thread while the GPU runs iteration i + 1 (same bytes, same order of files).
-    std::thread writer;
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{writer};   // also on the error path
     std::string writer_error;
     epv::FlatPaths out_paths;
     vector<double> out_branches;
     epv::SingleSiteSampler mcmc(burnin, batch,
                                 gpu_list.empty() ? epv::devices_from_env() : epv::parse_device_list(gpu_list));
+    // declared AFTER everything the thread references (and after the sampler): on an exception the
+    // join runs first, while out_paths, out_branches and writer_error are still alive, and the file
+    // of the last completed iteration is written out in full, as the synchronous reference leaves it
+    std::thread writer;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{writer};
     // EPV_CLI_TIMING=1: where the wall clock of the iterations went (stderr, at the end)
     const bool timing = std::getenv("EPV_CLI_TIMING") != nullptr;
     double t_reset = 0, t_mcmc = 0, t_mstep = 0, t_scale = 0, t_wait = 0, t_download = 0;
@@ -173,6 +180,10 @@ int main(int argc, const char **argv) {
 
       if (!param_file_updated.empty()) {
         std::ofstream out_param(param_file_updated);
+        // EPV_TEST_FAIL_PARAM_AT=k (tests): pretend the k-th rewrite failed, to exercise the error path
+        // while the previous iteration's paths file is still being written
+        const char *fail_at = std::getenv("EPV_TEST_FAIL_PARAM_AT");
+        if (fail_at && (size_t)std::atol(fail_at) == itr + 1) out_param.setstate(std::ios::failbit);
         if (!out_param) throw std::runtime_error("bad output param file: " + param_file_updated);
         out_param << the_model.format_for_param_file() << endl;
       }

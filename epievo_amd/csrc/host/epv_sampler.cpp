@@ -17,6 +17,16 @@ namespace {
 const uint64_t kBlock = 256;   // sites per level-0 block of the statistics tree
 const uint32_t kMaxCap = 2047;   // EPV_MAX_CAP: 2 C + 1 segments must fit the 12-bit segment field of the Philox address
 
+// worker threads that are joined on every exit path: if starting thread i + 1 throws
+// (std::system_error on thread exhaustion), the i threads already running are joined before the
+// exception leaves the scope instead of taking the process down through std::terminate
+struct ThreadGroup {
+  std::vector<std::thread> th;
+  template <class F> void spawn(F &&f) { th.emplace_back(std::forward<F>(f)); }
+  void join() { for (std::thread &t : th) if (t.joinable()) t.join(); }
+  ~ThreadGroup() { join(); }
+};
+
 uint64_t round_to(double x, uint64_t unit) { return (uint64_t)(x / (double)unit + 0.5) * unit; }
 
 // sites [lo, hi) of node-major flat paths
@@ -35,6 +45,31 @@ FlatPaths slice_sites(const FlatPaths &p, uint64_t lo, uint64_t hi) {
     q.jumps.insert(q.jumps.end(), p.jumps.begin() + j0, p.jumps.begin() + j1);
   }
   q.offsets[B * m] = q.jumps.size();
+  return q;
+}
+
+// columns [lo, hi) of a genome of which `p` holds [first, first + p.n_sites): columns outside
+// what is held come out blank (state 0, no jump) -- the halo columns of a slot whose neighbours
+// live in other processes, filled by the first halo exchange
+FlatPaths slice_sites_padded(const FlatPaths &p, uint64_t first, uint64_t lo, uint64_t hi) {
+  if (lo >= first && hi <= first + p.n_sites) return slice_sites(p, lo - first, hi - first);
+  const uint64_t a = std::max(lo, first), b = std::min(hi, first + p.n_sites);
+  const FlatPaths mid = slice_sites(p, a - first, b - first);
+  FlatPaths q;
+  q.n_sites = hi - lo;
+  q.n_nodes = p.n_nodes;
+  const uint64_t B = (uint64_t)p.n_nodes - 1, m = hi - lo, mm = mid.n_sites, pad = a - lo;
+  q.init.assign(B * m, 0);
+  q.offsets.assign(B * m + 1, 0);
+  q.jumps = mid.jumps;
+  for (uint64_t br = 0; br < B; ++br) {
+    std::copy(mid.init.begin() + br * mm, mid.init.begin() + (br + 1) * mm, q.init.begin() + br * m + pad);
+    for (uint64_t s2 = 0; s2 < m; ++s2) {
+      const uint64_t k = s2 < pad ? 0 : (s2 - pad < mm ? s2 - pad : mm);
+      q.offsets[br * m + s2] = mid.offsets[br * mm + k];
+    }
+  }
+  q.offsets[B * m] = mid.offsets[B * mm];
   return q;
 }
 
@@ -113,9 +148,49 @@ SingleSiteSampler::SingleSiteSampler(size_t n_burn_in, size_t n_batch, const std
   if (const char *e = std::getenv("EPV_FORCE_COMM")) force_comm_ = std::atoi(e) != 0;
 }
 
+SingleSiteSampler::SingleSiteSampler(size_t n_burn_in, size_t n_batch, const RankSpec &rank, uint32_t capacity)
+    : SingleSiteSampler(n_burn_in, n_batch, std::vector<int>(1, rank.device), capacity) {
+  if (rank.world < 1 || rank.rank < 0 || rank.rank >= rank.world) throw std::runtime_error("bad rank / world");
+  rank_mode_ = true;
+  rank_ = rank;
+  world_ = (size_t)rank.world;
+}
+
 SingleSiteSampler::~SingleSiteSampler() {
   drop_parts();
+  if (rank_comm_) epv_comm_destroy(rank_comm_);
   epv_destroy(ctx_);
+}
+
+std::vector<epv_ctx *> SingleSiteSampler::contexts() const {
+  std::vector<epv_ctx *> v;
+  if (parts_.empty()) v.push_back(ctx_);
+  for (const Part &p : parts_) v.push_back(p.ctx);
+  return v;
+}
+void SingleSiteSampler::set_options(uint32_t flags) {
+  for (epv_ctx *c : contexts()) check_on(c, epv_set_options(c, flags), "epv_set_options");
+}
+void SingleSiteSampler::set_timing(int every) {
+  for (epv_ctx *c : contexts()) check_on(c, epv_set_timing(c, every), "epv_set_timing");
+}
+void SingleSiteSampler::kernel_time_ms(double &avg_ms, uint64_t &n_launches) {
+  double tot = 0.0;
+  n_launches = 0;
+  for (epv_ctx *c : contexts()) {
+    double a = 0.0;
+    uint64_t k = 0;
+    check_on(c, epv_kernel_time_ms(c, &a, &k), "epv_kernel_time_ms");
+    tot += a * (double)k;
+    n_launches += k;
+  }
+  avg_ms = n_launches ? tot / (double)n_launches : 0.0;
+}
+uint32_t SingleSiteSampler::phase_mode() {
+  uint32_t m = 0;
+  epv_ctx *c = contexts()[0];
+  check_on(c, epv_phase_mode(c, &m), "epv_phase_mode");
+  return m;
 }
 
 void SingleSiteSampler::free_stat_buffers() {
@@ -134,7 +209,7 @@ void SingleSiteSampler::drop_parts() {
   for (Slot &s : slots_) {
     epv_ctx *c = parts_[s.part0].ctx;
     for (void *&p : s.d_halo) { if (p) epv_dev_free(c, p); p = nullptr; }
-    if (s.comm) epv_comm_destroy(s.comm);
+    if (s.comm && s.comm != rank_comm_) epv_comm_destroy(s.comm);
     s.comm = nullptr;
   }
   for (Part &p : parts_) if (p.ctx != ctx_) epv_destroy(p.ctx);
@@ -149,8 +224,10 @@ bool SingleSiteSampler::uses_rccl() const {
 std::string SingleSiteSampler::layout() const {
   std::ostringstream o;
   if (!sharded()) { o << "1 context on device " << devices_[0]; return o.str(); }
-  o << slots_.size() << " GPU slot(s) x up to " << contexts_per_gpu() << " context(s) = " << parts_.size()
-    << " parts, halo " << halo_ << " columns";
+  o << world_ << " GPU slot(s)";
+  if (rank_mode_) o << " (this process: slot " << rank_.rank << ")";
+  o << " x up to " << contexts_per_gpu() << " context(s) = " << parts_.size() << " parts"
+    << (rank_mode_ ? " here" : "") << ", halo " << halo_ << " columns";
   if (slots_[0].comm)
     o << ", statistics rows of " << kBlock * row_blocks_ << " sites, exchange over "
       << (uses_rccl() ? "RCCL" : "the loopback transport");
@@ -197,60 +274,72 @@ void SingleSiteSampler::refresh_parts() {
   const uint64_t H = halo_;
   equalize_capacity();
   const uint64_t bytes = H * epv_column_bytes(parts_[0].ctx);
-  bool any_cross = false;
+  // between two parts of one GPU: device-to-device copies
   for (size_t p = 0; p + 1 < P; ++p) {
     Part &L = parts_[p], &R = parts_[p + 1];
-    if (L.slot == R.slot) {
-      check_on(R.ctx, epv_copy_columns(L.ctx, L.b - H - L.lo, H, R.ctx, 0), "epv_copy_columns");
-      check_on(L.ctx, epv_copy_columns(R.ctx, H, H, L.ctx, L.b - L.lo), "epv_copy_columns");
-      continue;
-    }
-    any_cross = true;
-    for (Slot *s : {&slots_[L.slot], &slots_[R.slot]}) {
-      if (s->halo_bytes == bytes) continue;
-      epv_ctx *c = parts_[s->part0].ctx;
-      for (void *&q : s->d_halo) {
-        if (q) check_on(c, epv_dev_free(c, q), "epv_dev_free");
-        q = nullptr;
-        check_on(c, epv_dev_alloc(c, bytes, &q), "epv_dev_alloc");
-      }
-      s->halo_bytes = bytes;
-    }
-    check_on(L.ctx, epv_pack_columns_dev(L.ctx, L.b - H - L.lo, H, slots_[L.slot].d_halo[2]), "epv_pack_columns_dev");
-    check_on(R.ctx, epv_pack_columns_dev(R.ctx, H, H, slots_[R.slot].d_halo[0]), "epv_pack_columns_dev");
+    if (L.slot != R.slot) continue;
+    check_on(R.ctx, epv_copy_columns(L.ctx, L.b - H - L.lo, H, R.ctx, 0), "epv_copy_columns");
+    check_on(L.ctx, epv_copy_columns(R.ctx, H, H, L.ctx, L.b - L.lo), "epv_copy_columns");
   }
-  if (any_cross) {
-    const size_t G = slots_.size();
-    if (epv_comm_group_start() != EPV_OK) throw std::runtime_error("epv_comm_group_start failed");
-    for (size_t g = 0; g < G; ++g) {
-      Slot &s = slots_[g];
-      check_comm(s.comm, epv_comm_exchange(s.comm, s.d_halo[0], s.d_halo[1], g > 0 ? bytes : 0, s.d_halo[2],
-                                           s.d_halo[3], g + 1 < G ? bytes : 0), "epv_comm_exchange");
+  // between two GPU slots: the first part of a slot sends its left edge to the slot before it, the
+  // last part its right edge to the slot after it -- one exchange call per slot that lives here
+  // (all of them, or this process's one), the neighbours' calls pair up inside RCCL
+  if (world_ > 1) {
+    for (Slot &s : slots_) {
+      epv_ctx *c = parts_[s.part0].ctx;
+      if (s.halo_bytes != bytes) {
+        for (void *&q : s.d_halo) {
+          if (q) check_on(c, epv_dev_free(c, q), "epv_dev_free");
+          q = nullptr;
+          check_on(c, epv_dev_alloc(c, bytes, &q), "epv_dev_alloc");
+        }
+        s.halo_bytes = bytes;
+      }
+      Part &F = parts_[s.part0], &Lp = parts_[s.part1 - 1];
+      if (s.gidx > 0) check_on(F.ctx, epv_pack_columns_dev(F.ctx, F.a - F.lo, H, s.d_halo[0]), "epv_pack_columns_dev");
+      if (s.gidx + 1 < world_)
+        check_on(Lp.ctx, epv_pack_columns_dev(Lp.ctx, Lp.b - H - Lp.lo, H, s.d_halo[2]), "epv_pack_columns_dev");
     }
+    if (epv_comm_group_start() != EPV_OK) throw std::runtime_error("epv_comm_group_start failed");
+    for (Slot &s : slots_)
+      check_comm(s.comm, epv_comm_exchange(s.comm, s.d_halo[0], s.d_halo[1], s.gidx > 0 ? bytes : 0, s.d_halo[2],
+                                           s.d_halo[3], s.gidx + 1 < world_ ? bytes : 0), "epv_comm_exchange");
     if (epv_comm_group_end() != EPV_OK) throw std::runtime_error("epv_comm_group_end failed (halo exchange)");
     for (Slot &s : slots_) check_comm(s.comm, epv_comm_sync(s.comm), "epv_comm_sync");
-    for (size_t p = 0; p + 1 < P; ++p) {
-      Part &L = parts_[p], &R = parts_[p + 1];
-      if (L.slot == R.slot) continue;
-      check_on(L.ctx, epv_unpack_columns_dev(L.ctx, L.b - L.lo, H, slots_[L.slot].d_halo[3]), "epv_unpack_columns_dev");
-      check_on(R.ctx, epv_unpack_columns_dev(R.ctx, 0, H, slots_[R.slot].d_halo[1]), "epv_unpack_columns_dev");
+    for (Slot &s : slots_) {
+      Part &F = parts_[s.part0], &Lp = parts_[s.part1 - 1];
+      if (s.gidx > 0) check_on(F.ctx, epv_unpack_columns_dev(F.ctx, 0, H, s.d_halo[1]), "epv_unpack_columns_dev");
+      if (s.gidx + 1 < world_)
+        check_on(Lp.ctx, epv_unpack_columns_dev(Lp.ctx, Lp.b - Lp.lo, H, s.d_halo[3]), "epv_unpack_columns_dev");
     }
   }
-  for (size_t p = 0; p < P; ++p)
-    check_on(parts_[p].ctx, epv_set_halo(parts_[p].ctx, p == 0 ? 0 : H, p + 1 == P ? 0 : H), "epv_set_halo");
+  for (size_t p = 0; p < P; ++p) {
+    const bool first = parts_[p].lo == parts_[p].a, last = parts_[p].hi == parts_[p].b;   // the genome's ends
+    check_on(parts_[p].ctx, epv_set_halo(parts_[p].ctx, first ? 0 : H, last ? 0 : H), "epv_set_halo");
+  }
 }
 
-void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &paths) {
-  n_nodes_ = th.n_nodes();
-  n_sites_ = paths.n_sites;
-  drop_parts();
-  const uint64_t n = paths.n_sites;
-  // a halo that lasts one whole run_mcmc (two columns per colour phase), in whole blocks
-  const uint64_t H = std::max<uint64_t>(kBlock, (6 * (uint64_t)(burn_in + batch) + 2 + kBlock - 1) / kBlock * kBlock);
+// SAMPLE_ROOT (a public field of the reference class, hard-wired false at SingleSiteSampler.cpp:441 and
+// set by none of its programs) would resample the root state (:167-176, :246-249).  The kernels
+// keep the root state -- their exact proposal ratio holds only then -- so a caller that sets the
+// field is refused instead of silently getting the other chain.
+static void refuse_sample_root(bool sample_root) {
+  if (sample_root)
+    throw std::runtime_error("SingleSiteSampler::SAMPLE_ROOT = true is not supported by the MI355X sampler "
+                             "(root states are kept, as in every program of the reference)");
+}
+
+// a halo that lasts one whole run_mcmc (two columns per colour phase), in whole blocks
+static uint64_t halo_for(size_t n_burn_in, size_t n_batch) {
+  return std::max<uint64_t>(kBlock, (6 * (uint64_t)(n_burn_in + n_batch) + 2 + kBlock - 1) / kBlock * kBlock);
+}
+
+std::vector<uint64_t> SingleSiteSampler::shard_cuts(uint64_t n, size_t world, size_t n_burn_in, size_t n_batch,
+                                                    uint32_t row_blocks) {
+  const uint64_t H = halo_for(n_burn_in, n_batch);
   const uint64_t min_part = 2 * H + 2 * kBlock;     // every part must own more than its halos
-  const uint64_t RS = kBlock * row_blocks_;
-  // slots: as many of the requested GPUs as the genome can feed, cut on whole statistics rows
-  size_t G = devices_.size();
+  const uint64_t RS = kBlock * row_blocks;
+  size_t G = std::max<size_t>(1, world);
   std::vector<uint64_t> cut;
   for (;; --G) {
     cut.assign(G + 1, 0);
@@ -260,49 +349,99 @@ void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &p
     for (size_t g = 0; g < G && ok; ++g) ok = cut[g + 1] > cut[g] && cut[g + 1] - cut[g] >= min_part;
     if (ok || G == 1) break;
   }
+  return cut;
+}
+
+void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &paths) {
+  refuse_sample_root(SAMPLE_ROOT);
+  if (rank_mode_) throw std::runtime_error("one slot per process: reset(model, tree, owned columns, n_global)");
+  build(th, paths, paths.n_sites, false);
+  reset(m);
+}
+
+void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &owned, uint64_t n_global) {
+  refuse_sample_root(SAMPLE_ROOT);
+  if (!rank_mode_) throw std::runtime_error("reset(..., n_global) belongs to the one-slot-per-process constructor");
+  build(th, owned, n_global, true);
+  reset(m);
+}
+
+void SingleSiteSampler::build(const Tree &th, const FlatPaths &paths, uint64_t n, bool rank_mode) {
+  n_nodes_ = th.n_nodes();
+  n_sites_ = n;
+  drop_parts();
+  const uint64_t H = halo_for(burn_in, batch);
+  const uint64_t min_part = 2 * H + 2 * kBlock;
+  // slots: as many of the requested GPUs as the genome can feed, cut on whole statistics rows
+  const std::vector<uint64_t> cut = shard_cuts(n, rank_mode ? world_ : devices_.size(), burn_in, batch, row_blocks_);
+  const size_t G = cut.size() - 1;
+  if (rank_mode && G != world_)
+    throw std::runtime_error("a genome of " + std::to_string(n) + " sites cannot feed " + std::to_string(world_) + " GPU slots");
+  world_ = G;
+  // the slots that live in this process, and the columns of the genome `paths` holds
+  const size_t g_lo = rank_mode ? (size_t)rank_.rank : 0, g_hi = rank_mode ? (size_t)rank_.rank + 1 : G;
+  const uint64_t held_first = rank_mode ? cut[g_lo] : 0;
+  if (rank_mode && paths.n_sites != cut[g_lo + 1] - cut[g_lo])
+    throw std::runtime_error("slot " + std::to_string(g_lo) + " owns " + std::to_string(cut[g_lo + 1] - cut[g_lo]) +
+                             " columns (shard_cuts), got " + std::to_string(paths.n_sites));
   struct Piece { size_t slot; uint64_t a, b; };
   std::vector<Piece> pieces;
-  for (size_t g = 0; g < G; ++g) {
+  for (size_t g = g_lo; g < g_hi; ++g) {
     const uint64_t len = cut[g + 1] - cut[g];
     size_t k = (size_t)contexts_per_gpu();
     while (k > 1 && len < k * min_part) --k;
     for (size_t j = 0; j < k; ++j) {
       const uint64_t a = j == 0 ? cut[g] : cut[g] + round_to((double)j * (double)len / (double)k, kBlock);
       const uint64_t b = j + 1 == k ? cut[g + 1] : cut[g] + round_to((double)(j + 1) * (double)len / (double)k, kBlock);
-      pieces.push_back({g, a, b});
+      pieces.push_back({g - g_lo, a, b});
     }
   }
-  if (pieces.size() == 1 && !force_comm_) {
+  if (pieces.size() == 1 && G == 1 && !force_comm_) {
     check(epv_set_tree(ctx_, th.n_nodes(), th.parent_ids.data(), th.subtree_sizes.data(),
                        th.branches.data()), "epv_set_tree");
     check(epv_upload_paths(ctx_, paths.n_sites, paths.init.data(), paths.offsets.data(),
                            paths.jumps.data(), capacity_, 0), "epv_upload_paths");
-    reset(m);
     return;
   }
   uint32_t cap = capacity_;
   if (cap == 0) {   // the library's default rule, evaluated once for the whole genome
+    if (rank_mode) {
+      cap = 16;     // the slots cannot see each other's inputs: start narrow, widen on demand like every overflow
+    } else {
+      uint64_t maxj = 0;
+      for (size_t e = 0; e + 1 < paths.offsets.size(); ++e) maxj = std::max(maxj, paths.offsets[e + 1] - paths.offsets[e]);
+      cap = (uint32_t)std::min<uint64_t>(kMaxCap, std::max<uint64_t>(16, 2 * maxj + 8));
+    }
+  }
+  if (rank_mode) {   // every slot must propose under one capacity: at least what its own input needs
     uint64_t maxj = 0;
     for (size_t e = 0; e + 1 < paths.offsets.size(); ++e) maxj = std::max(maxj, paths.offsets[e + 1] - paths.offsets[e]);
-    cap = (uint32_t)std::min<uint64_t>(kMaxCap, std::max<uint64_t>(16, 2 * maxj + 8));
+    if (maxj > cap) throw std::runtime_error("one slot per process: pass a capacity of at least " + std::to_string(maxj));
   }
   halo_ = H;
-  slots_.resize(G);
-  for (size_t g = 0; g < G; ++g) {
-    slots_[g].device = devices_[g];
-    slots_[g].first = cut[g];
-    slots_[g].last = cut[g + 1];
-    slots_[g].n_blocks = (cut[g + 1] - cut[g] + kBlock - 1) / kBlock;
-    slots_[g].n_rows = (slots_[g].n_blocks + row_blocks_ - 1) / row_blocks_;
+  slots_.resize(g_hi - g_lo);
+  for (size_t g = g_lo; g < g_hi; ++g) {
+    Slot &sl = slots_[g - g_lo];
+    sl.device = devices_[g - g_lo];
+    sl.gidx = g;
+    sl.first = cut[g];
+    sl.last = cut[g + 1];
+    sl.n_blocks = (cut[g + 1] - cut[g] + kBlock - 1) / kBlock;
+    sl.n_rows = (sl.n_blocks + row_blocks_ - 1) / row_blocks_;
   }
+  max_rows_ = 0;   // the same on every process: all slots of the run
+  for (size_t g = 0; g < G; ++g)
+    max_rows_ = std::max<uint64_t>(max_rows_, ((cut[g + 1] - cut[g] + kBlock - 1) / kBlock + row_blocks_ - 1) / row_blocks_);
+  rows_of_slot_.assign(G, 0);
+  for (size_t g = 0; g < G; ++g) rows_of_slot_[g] = ((cut[g + 1] - cut[g] + kBlock - 1) / kBlock + row_blocks_ - 1) / row_blocks_;
   const size_t P = pieces.size();
   for (size_t p = 0; p < P; ++p) {
     Part q;
     q.slot = pieces[p].slot;
     q.a = pieces[p].a;
     q.b = pieces[p].b;
-    q.lo = q.a - (p > 0 ? H : 0);
-    q.hi = q.b + (p + 1 < P ? H : 0);
+    q.lo = q.a - (q.a > 0 ? H : 0);
+    q.hi = q.b + (q.b < n ? H : 0);
     if (p == 0) {
       q.ctx = ctx_;
     } else {
@@ -316,13 +455,19 @@ void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &p
     epv_ctx *c = q.ctx;
     check_on(c, epv_set_tree(c, th.n_nodes(), th.parent_ids.data(), th.subtree_sizes.data(), th.branches.data()),
              "epv_set_tree");
-    const FlatPaths part = slice_sites(paths, q.lo, q.hi);
+    const FlatPaths part = slice_sites_padded(paths, held_first, q.lo, q.hi);
     const double dummy = 0.0;
     check_on(c, epv_upload_paths(c, part.n_sites, part.init.data(), part.offsets.data(),
                                  part.jumps.empty() ? &dummy : part.jumps.data(), cap, q.lo), "epv_upload_paths");
     check_on(c, epv_set_global_length(c, n), "epv_set_global_length");
   }
-  if (G > 1 || force_comm_) {
+  if (rank_mode) {
+    // one communicator rank in this process, made once (an RCCL id serves one ncclCommInitRank)
+    if (!rank_comm_ && epv_comm_init_rank(rank_.device, rank_.world, rank_.rank, rank_.id, &rank_comm_) != EPV_OK)
+      throw std::runtime_error("cannot join the RCCL communicator as rank " + std::to_string(rank_.rank) + " of " +
+                               std::to_string(rank_.world));
+    slots_[0].comm = rank_comm_;
+  } else if (G > 1 || force_comm_) {
     // one communicator rank per slot, all driven from this process: RCCL over the node's xGMI
     // links when the devices are distinct, the loopback transport when they repeat
     std::vector<int> devs(G);
@@ -332,7 +477,6 @@ void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &p
       throw std::runtime_error("cannot set up the RCCL communicator over " + std::to_string(G) + " GPU slot(s)");
     for (size_t g = 0; g < G; ++g) slots_[g].comm = comms[g];
   }
-  reset(m);
 }
 
 void SingleSiteSampler::init_paths_indep(const Model &m, const Tree &th, const std::vector<uint8_t> &root_seq,
@@ -350,6 +494,7 @@ void SingleSiteSampler::init_paths_indep(const Model &m, const Tree &th, const s
 }
 
 void SingleSiteSampler::reset(const Model &m) {
+  refuse_sample_root(SAMPLE_ROOT);
   if (!sharded()) {
     check(epv_set_model(ctx_, m.rates.data(), m.T.data()), "epv_set_model");
     check(epv_reset(ctx_), "epv_reset");
@@ -359,28 +504,30 @@ void SingleSiteSampler::reset(const Model &m) {
   refresh_parts();
   // the parts' cached likelihoods, each on its own stream from its own host thread
   std::vector<std::string> errors(parts_.size());
-  std::vector<std::thread> workers;
+  ThreadGroup workers;
   for (size_t i = 0; i < parts_.size(); ++i)
-    workers.emplace_back([this, i, &errors] {
+    workers.spawn([this, i, &errors] {
       try { check_on(parts_[i].ctx, epv_reset(parts_[i].ctx), "epv_reset"); }
       catch (const std::exception &e) { errors[i] = e.what(); }
     });
-  for (std::thread &w : workers) w.join();
+  workers.join();
   for (const std::string &e : errors) if (!e.empty()) throw std::runtime_error(e);
 }
+
+// words appended to a slot's rows in the all-gather: its accept count
+static const uint64_t kTail = 8;
 
 void SingleSiteSampler::ensure_stat_buffers() {
   if (stat_batch_ >= batch && slots_[0].d_blocks) return;
   free_stat_buffers();
   const uint64_t V = ((uint64_t)n_nodes_ - 1) * 16;
-  max_rows_ = 0;
-  for (Slot &s : slots_) max_rows_ = std::max(max_rows_, s.n_rows);
   for (Slot &s : slots_) {
     epv_ctx *c = parts_[s.part0].ctx;
     check_on(c, epv_dev_alloc(c, batch * s.n_blocks * V * sizeof(double), &s.d_blocks), "epv_dev_alloc");
     if (s.comm) {
-      check_on(c, epv_dev_alloc(c, max_rows_ * batch * V * sizeof(double), &s.d_rows), "epv_dev_alloc");
-      check_on(c, epv_dev_alloc(c, slots_.size() * max_rows_ * batch * V * sizeof(double), &s.d_gather), "epv_dev_alloc");
+      const uint64_t piece = max_rows_ * batch * V + kTail;
+      check_on(c, epv_dev_alloc(c, piece * sizeof(double), &s.d_rows), "epv_dev_alloc");
+      check_on(c, epv_dev_alloc(c, world_ * piece * sizeof(double), &s.d_gather), "epv_dev_alloc");
     }
   }
   stat_batch_ = batch;
@@ -389,6 +536,7 @@ void SingleSiteSampler::ensure_stat_buffers() {
 void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
                                  std::vector<std::vector<double>> &J,
                                  std::vector<std::vector<double>> &D, double &acceptance_rate) {
+  refuse_sample_root(SAMPLE_ROOT);
   const size_t B = (size_t)n_nodes_ - 1;
   std::vector<double> Jf(B * 8), Df(B * 8);
   uint64_t n_acc = 0;
@@ -402,15 +550,15 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
     const size_t P = parts_.size();
     std::vector<int> rcs(P, EPV_OK);
     std::vector<uint64_t> acc(P, 0);
-    std::vector<std::thread> th;
+    ThreadGroup th;
     for (size_t p = 0; p < P; ++p)
-      th.emplace_back([&, p] {
+      th.spawn([&, p] {
         const Part &q = parts_[p];
         const Slot &s = slots_[q.slot];
         rcs[p] = epv_run_mcmc_blocks(q.ctx, burn_in, batch, seed, base, static_cast<double *>(s.d_blocks),
                                      s.n_blocks, ((int64_t)q.lo - (int64_t)s.first) / (int64_t)kBlock, &acc[p]);
       });
-    for (std::thread &t : th) t.join();
+    th.join();
     for (size_t p = 0; p < P; ++p) {
       epv_ctx *c = parts_[p].ctx;
       if (rcs[p] == EPV_ERR_CAPACITY) {   // absorbed as in check_mcmc; refresh_parts() evens the widths out
@@ -429,24 +577,33 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
       check(epv_reduce_blocks(ctx_, static_cast<const double *>(s.d_blocks), s.n_blocks, batch, 1, Jf.data(), Df.data()),
             "epv_reduce_blocks");
     } else {
-      // the one collective of an EM iteration: every GPU's rows of the statistics tree
-      const size_t G = slots_.size();
-      const uint64_t row_bytes = batch * B * 16 * sizeof(double);
+      // the one collective of an EM iteration: every GPU's rows of integer statistics, its accept
+      // count riding in the tail of its piece
+      const uint64_t row_words = batch * B * 16, piece = max_rows_ * row_words + kTail;
       for (Slot &s : slots_) {
         epv_ctx *c = parts_[s.part0].ctx;
         check_on(c, epv_blocks_to_rows(c, static_cast<const double *>(s.d_blocks), s.n_blocks, batch, row_blocks_,
                                        static_cast<double *>(s.d_rows)), "epv_blocks_to_rows");
+        uint64_t acc_slot = 0;
+        for (size_t p = s.part0; p < s.part1; ++p) acc_slot += acc[p];
+        check_on(c, epv_dev_write(c, static_cast<double *>(s.d_rows) + max_rows_ * row_words, &acc_slot, sizeof acc_slot),
+                 "epv_dev_write");
       }
       if (epv_comm_group_start() != EPV_OK) throw std::runtime_error("epv_comm_group_start failed");
       for (Slot &s : slots_)
-        check_comm(s.comm, epv_comm_all_gather(s.comm, s.d_rows, s.d_gather, max_rows_ * row_bytes), "epv_comm_all_gather");
+        check_comm(s.comm, epv_comm_all_gather(s.comm, s.d_rows, s.d_gather, piece * sizeof(double)), "epv_comm_all_gather");
       if (epv_comm_group_end() != EPV_OK) throw std::runtime_error("epv_comm_group_end failed (statistics all-gather)");
       for (Slot &s : slots_) check_comm(s.comm, epv_comm_sync(s.comm), "epv_comm_sync");
-      std::vector<uint64_t> rows(G);
-      for (size_t g = 0; g < G; ++g) rows[g] = slots_[g].n_rows;
       // every GPU now holds the same rows; the host M-step needs one copy of the totals
-      check(epv_reduce_gathered_rows(ctx_, static_cast<const double *>(slots_[0].d_gather), (uint32_t)G, max_rows_, 0,
-                                     rows.data(), batch, 1, Jf.data(), Df.data()), "epv_reduce_gathered_rows");
+      check(epv_reduce_gathered_rows(ctx_, static_cast<const double *>(slots_[0].d_gather), (uint32_t)world_, max_rows_, piece,
+                                     rows_of_slot_.data(), batch, 1, Jf.data(), Df.data()), "epv_reduce_gathered_rows");
+      n_acc = 0;
+      for (size_t g = 0; g < world_; ++g) {
+        uint64_t v = 0;
+        check(epv_dev_read(ctx_, &v, static_cast<const double *>(slots_[0].d_gather) + g * piece + max_rows_ * row_words, sizeof v),
+              "epv_dev_read");
+        n_acc += v;
+      }
     }
   }
   J.assign(n_nodes_, {});
@@ -459,6 +616,7 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
 }
 
 size_t SingleSiteSampler::sweeps(size_t n, uint64_t seed, uint32_t sweep_base) {
+  refuse_sample_root(SAMPLE_ROOT);
   uint64_t n_acc = 0;
   if (!sharded()) {
     check_mcmc(epv_sweep(ctx_, n, seed, sweep_base, &n_acc), "epv_sweep");
@@ -478,10 +636,10 @@ size_t SingleSiteSampler::sweeps(size_t n, uint64_t seed, uint32_t sweep_base) {
     const size_t P = parts_.size();
     std::vector<int> rcs(P, EPV_OK);
     std::vector<uint64_t> acc(P, 0);
-    std::vector<std::thread> th;
+    ThreadGroup th;
     for (size_t p = 0; p < P; ++p)
-      th.emplace_back([&, p] { rcs[p] = epv_sweep(parts_[p].ctx, kk, seed, sweep_base + (uint32_t)done, &acc[p]); });
-    for (std::thread &t : th) t.join();
+      th.spawn([&, p] { rcs[p] = epv_sweep(parts_[p].ctx, kk, seed, sweep_base + (uint32_t)done, &acc[p]); });
+    th.join();
     bool grew = false;
     for (size_t p = 0; p < P; ++p) {
       epv_ctx *c = parts_[p].ctx;
@@ -561,9 +719,9 @@ void SingleSiteSampler::download(FlatPaths &paths) {
     // every part on its own host thread (its context has its own stream): gather, copy, trim halos
     std::vector<FlatPaths> owned(parts_.size());
     std::vector<std::string> errors(parts_.size());
-    std::vector<std::thread> workers;
+    ThreadGroup workers;
     for (size_t i = 0; i < parts_.size(); ++i)
-      workers.emplace_back([this, i, &owned, &errors] {
+      workers.spawn([this, i, &owned, &errors] {
         try {
           Part &q = parts_[i];
           epv_ctx *c = q.ctx;
@@ -581,7 +739,7 @@ void SingleSiteSampler::download(FlatPaths &paths) {
           owned[i] = slice_sites(p, q.a - q.lo, q.b - q.lo);
         } catch (const std::exception &e) { errors[i] = e.what(); }
       });
-    for (std::thread &w : workers) w.join();
+    workers.join();
     for (const std::string &e : errors) if (!e.empty()) throw std::runtime_error(e);
     paths = concat_sites(owned);
     return;

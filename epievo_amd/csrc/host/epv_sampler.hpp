@@ -25,6 +25,15 @@
 // one-context run for any G and k.  A device list with repeats
 // (EPV_DEVICES=0,0,0,0) rehearses an N-GPU run on a smaller box through the loopback transport
 // of the exchange layer.
+//
+// Two ways to place the GPU slots (include/epievo_mi355x_comm.h):
+//   * every slot in THIS process (the CLIs, `bench.py --gpus N` called plainly): the constructor's
+//     device list, one RCCL communicator rank per slot through ncclCommInitAll;
+//   * one slot per process (RankSpec; torchrun-style launchers): the process owns slot `rank` of
+//     `world`, reset() takes the OWNED columns of that slot (shard_cuts tells which), the halo
+//     columns arrive from the neighbouring ranks before the first reset, and the communicator
+//     comes from ncclCommInitRank with an id the launcher passes around.
+// Both run the same code below; the loops simply cover the slots that live here.
 #ifndef EPV_SAMPLER_HPP
 #define EPV_SAMPLER_HPP
 
@@ -46,10 +55,23 @@ std::vector<int> parse_device_list(const std::string &spec);
 // the device list of the environment (EPV_DEVICES), {0} when unset
 std::vector<int> devices_from_env();
 
+// one slot of a run whose other slots live in other processes
+struct RankSpec {
+  int device = 0;           // the GPU of this process
+  int world = 1, rank = 0;  // slots of the run, and this one's place in genome order
+  unsigned char id[128] = {0};   // epv_comm_get_unique_id of rank 0, passed around by the launcher
+};
+
 class SingleSiteSampler {
 public:
   SingleSiteSampler(size_t n_burn_in, size_t n_batch, int device = 0, uint32_t capacity = 0);
   SingleSiteSampler(size_t n_burn_in, size_t n_batch, const std::vector<int> &devices, uint32_t capacity = 0);
+  SingleSiteSampler(size_t n_burn_in, size_t n_batch, const RankSpec &rank, uint32_t capacity = 0);
+  // cut points of `world` contiguous slots of an n-site genome (whole statistics rows of
+  // 256 * row_blocks sites; every slot must be able to hold its halos): world + 1 entries, or fewer
+  // when the genome cannot feed that many slots
+  static std::vector<uint64_t> shard_cuts(uint64_t n_sites, size_t world, size_t n_burn_in, size_t n_batch,
+                                          uint32_t row_blocks = 64);
   ~SingleSiteSampler();
   SingleSiteSampler(const SingleSiteSampler &) = delete;
   SingleSiteSampler &operator=(const SingleSiteSampler &) = delete;
@@ -57,6 +79,8 @@ public:
   // SingleSiteSampler::reset (SingleSiteSampler.cpp:449-475)
   void reset(const Model &the_model, const Tree &th, const FlatPaths &paths);
   void reset(const Model &the_model);
+  // one slot per process: `owned` = the columns [cuts[rank], cuts[rank + 1]) of an n_global-site genome
+  void reset(const Model &the_model, const Tree &th, const FlatPaths &owned, uint64_t n_global);
 
   // initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device for the
   // two-node tree `th`; afterwards the paths are resident as after reset(model, th, paths)
@@ -75,7 +99,14 @@ public:
   // scale_jump_times (ParamEstimation.cpp:369-380)
   void scale_jump_times(const std::vector<double> &new_branches);
 
+  // the resident paths (one slot per process: the owned columns of this slot)
   void download(FlatPaths &paths);
+  // EPV_OPT_* of include/epievo_mi355x.h on every context; HIP-event timing of the colour phases
+  void set_options(uint32_t flags);
+  void set_timing(int every);
+  void kernel_time_ms(double &avg_ms, uint64_t &n_launches);
+  uint32_t phase_mode();
+  uint64_t halo_columns() const { return halo_; }
 
   // upload paths without touching the model (the site-independent stage has no EpiEvoModel yet)
   void upload(const Tree &th, const FlatPaths &paths);
@@ -88,7 +119,8 @@ public:
   void indep_update_paths(const double rates[2], uint64_t seed, uint32_t sweep);
 
   // MCMC parameter constants (public fields of the reference class)
-  bool SAMPLE_ROOT;  // hard-wired false in the reference (SingleSiteSampler.cpp:441)
+  bool SAMPLE_ROOT;  // hard-wired false in the reference (SingleSiteSampler.cpp:441); true is REFUSED
+                     // (std::runtime_error from reset / run_mcmc / sweeps): the kernels keep the root state
   size_t burn_in;
   size_t batch;
 
@@ -108,8 +140,9 @@ private:
     size_t slot = 0;
     uint64_t lo = 0, a = 0, b = 0, hi = 0;
   };
-  struct Slot {            // one GPU of the run (or one rehearsal slot on a shared GPU)
+  struct Slot {            // one GPU of the run (or one rehearsal slot on a shared GPU) that lives here
     int device = 0;
+    size_t gidx = 0;                     // its place among the run's slots
     epv_comm *comm = nullptr;
     uint64_t first = 0, last = 0;        // owned columns [first, last) of the genome
     size_t part0 = 0, part1 = 0;         // its parts [part0, part1)
@@ -127,6 +160,8 @@ private:
   bool sharded() const { return !parts_.empty(); }
   void drop_parts();          // back to the single context ctx_
   void refresh_parts();       // equal capacities, halo columns of every inner edge, fresh halo marks
+  void build(const Tree &th, const FlatPaths &paths, uint64_t n_global, bool rank_mode);
+  std::vector<epv_ctx *> contexts() const;
   void equalize_capacity();
   void ensure_stat_buffers();
   void free_stat_buffers();
@@ -139,9 +174,14 @@ private:
   std::vector<Slot> slots_;
   uint64_t halo_ = 0;         // halo columns at every inner edge (multiple of 256)
   uint64_t max_rows_ = 0, stat_batch_ = 0;
+  std::vector<uint64_t> rows_of_slot_;   // statistics rows of every slot of the run
   uint32_t capacity_;
   int n_nodes_ = 0;
-  uint64_t n_sites_ = 0;
+  uint64_t n_sites_ = 0;      // genome length (all slots)
+  size_t world_ = 1;          // slots of the run (== slots_.size() unless one slot per process)
+  bool rank_mode_ = false;
+  RankSpec rank_;
+  epv_comm *rank_comm_ = nullptr;   // one slot per process: the communicator outlives the parts
 };
 
 }  // namespace epv

@@ -433,13 +433,21 @@ class SingleSiteSampler:
 
     def __init__(self, n_burn_in, n_batch, device=0, capacity=0):
         self.burn_in, self.batch = int(n_burn_in), int(n_batch)
-        self.SAMPLE_ROOT = False  # hard-wired false in the reference (SingleSiteSampler.cpp:441)
+        # hard-wired false in the reference (SingleSiteSampler.cpp:441) and set by none of its programs;
+        # True is REFUSED by reset / run_mcmc / sweeps: the kernels keep the root state
+        self.SAMPLE_ROOT = False
         self.capacity = capacity
         self.dev = DeviceSampler(device)
         self.dev.auto_grow = True     # paths grow on demand, as the reference's vectors do
         self._uploaded = False
 
+    def _refuse_sample_root(self):
+        if self.SAMPLE_ROOT:
+            raise EpvError(EPV_ERR_ARG, "SingleSiteSampler.SAMPLE_ROOT = True is not supported by the MI355X "
+                                        "sampler (root states are kept, as in every program of the reference)")
+
     def reset(self, model, tree, paths=None):
+        self._refuse_sample_root()
         self.dev.set_tree(tree)
         self.dev.set_model(model)
         if paths is not None:
@@ -450,12 +458,14 @@ class SingleSiteSampler:
         self.dev.reset()
 
     def run_mcmc(self, seed, em_iter=0):
+        self._refuse_sample_root()
         base = em_iter * (self.burn_in + self.batch)
         J, D, nacc = self.dev.run_mcmc(self.burn_in, self.batch, seed, base)
         acc_rate = nacc / float(self.batch * (self.dev.n_sites - 2))
         return J, D, acc_rate
 
     def sweeps(self, n, seed, sweep_base=0):
+        self._refuse_sample_root()
         return self.dev.sweep(n, seed, sweep_base)
 
     def scale_jump_times(self, new_branches):

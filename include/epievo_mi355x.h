@@ -63,8 +63,14 @@ typedef struct {
  *     (end_cond_sample_forward_rejection, EndCondSampling.cpp:479-509, the sampler the
  *     reference's hot path calls) instead of the reference library's
  *     end_cond_sampling_Nielsen (:576-617), the default here because its acceptance probability
- *     does not vanish on short branches.  Same conditional law; for parity tests. */
-enum { EPV_OPT_REFERENCE_PROPOSAL_RATIO = 1, EPV_OPT_FORWARD_REJECTION = 2 };
+ *     does not vanish on short branches.  Same conditional law; for parity tests.
+ * EPV_OPT_SAMPLE_ROOT  the reference class's public field SAMPLE_ROOT (SingleSiteSampler.hpp:78;
+ *     root_post_prob0 / downward_sampling, SingleSiteSampler.cpp:167-176, :246-249).  It is
+ *     hard-wired false (:441) and none of the reference's programs sets it; the kernels keep the
+ *     root state and their exact proposal ratio holds only then.  The bit is RESERVED so that a
+ *     binding can forward the field: epv_set_options refuses it with EPV_ERR_ARG (as the C++ and
+ *     Python mirrors refuse SAMPLE_ROOT = true) instead of silently running the other chain. */
+enum { EPV_OPT_REFERENCE_PROPOSAL_RATIO = 1, EPV_OPT_FORWARD_REJECTION = 2, EPV_OPT_SAMPLE_ROOT = 4 };
 
 /* Create a context on HIP device `device_id`.  Returns NULL when the device cannot be
  * initialised (the product has no CPU fallback).  Replaces
@@ -190,7 +196,12 @@ int epv_run_mcmc_sums(epv_ctx *ctx, uint64_t burn_in, uint64_t batch, uint64_t s
                       uint64_t *n_accepted);
 
 /* get_sufficient_statistics, per-branch overload (ParamEstimation.cpp:92-114), over
- * the update range's triples, reduced in the canonical binary-tree order. */
+ * the update range's triples.  The sums are EXACT integers on the device -- J as counts, every
+ * dwell time of branch b as rint(dt * 2^k_b) with k_b = min(61 - e(n_global * T_b), 50 - e(T_b)),
+ * e(x) the frexp exponent -- and become doubles on the host (D = integer * 2^-k_b): the result
+ * does not depend on the launch shape, the number of contexts or GPUs, or any summation order,
+ * and lies within 2^-41 T_b per term of the exact sum at n = 1e6 (closer than a sequential
+ * fp64 sum). */
 int epv_get_sufficient_statistics(epv_ctx *ctx, double *J, double *D);
 
 /* scale_jump_times (ParamEstimation.cpp:369-380): jumps *= new/old per branch. */
@@ -223,13 +234,14 @@ int epv_copy_columns(epv_ctx *src, uint64_t src_first, uint64_t count, epv_ctx *
 /* ---- several shards on one GPU (new; the reference is single-process).  Two or three
  * contexts on one device, each owning a contiguous range of 256-aligned site blocks plus
  * redundant halos, run their colour phases on their own streams so that the ramps and tails
- * of the dependent kernels overlap (+17 % on one MI355X).  To keep J AND D bit-identical to the
- * unsharded run the statistics are not reduced per shard: every shard writes the level-0
- * partials of its OWNED 256-site blocks, per batch sweep, into one buffer shared by the group
- * (epv_run_mcmc_blocks; d_blocks[w][block][16 (N-1)] doubles, block_offset = index of the
- * shard's local block 0 in the group -- negative when a halo precedes the first owned block of
- * the buffer; the shard's global_site_offset must be a multiple of 256), and one canonical reduction (epv_reduce_blocks, on any
- * context of the group) adds them up exactly as run_mcmc does on one context.
+ * of the dependent kernels overlap (+17 % on one MI355X).  Every shard writes the integer
+ * partial sums (see epv_get_sufficient_statistics) of its OWNED 256-site blocks, per batch sweep,
+ * into one buffer shared by the group (epv_run_mcmc_blocks; d_blocks[w][block][16 (N-1)] 64-bit
+ * words -- int64 behind the double pointer, J counts then fixed-point D; block_offset = index of
+ * the shard's local block 0 in the group -- negative when a halo precedes the first owned block of
+ * the buffer; the shard's global_site_offset must be a multiple of 256), and one reduction
+ * (epv_reduce_blocks, on any context of the group) adds them up.  Integer sums are exact, so J AND
+ * D equal the one-context run bit for bit however the genome is cut.
  * epv_dev_alloc returns zero-filled device memory (blocks nobody owns must read as 0). */
 int epv_dev_alloc(epv_ctx *ctx, uint64_t bytes, void **device_ptr);
 int epv_dev_free(epv_ctx *ctx, void *device_ptr);
@@ -245,9 +257,8 @@ int epv_reduce_blocks(epv_ctx *ctx, const double *d_blocks, uint64_t n_blocks_to
  * 256 * row_blocks sites (row_blocks a power of two).  Every GPU reduces the level-0 partials of
  * ITS blocks (d_blocks as written by epv_run_mcmc_blocks, nb_total blocks) to rows of row_blocks
  * blocks, d_rows[row][w][16 (N-1)]; the rows of all GPUs, concatenated in genome order (one RCCL
- * all-gather per EM iteration), go through epv_reduce_rows.  Every stage is a piece of the same
- * balanced binary tree over the site index, so J AND D equal the one-context results bit for
- * bit, whatever the number of GPUs. */
+ * all-gather per EM iteration), go through epv_reduce_rows.  Every stage adds 64-bit integers, so
+ * J AND D equal the one-context results bit for bit, whatever the number of GPUs and rows. */
 int epv_blocks_to_rows(epv_ctx *ctx, const double *d_blocks, uint64_t n_blocks_total, uint64_t batch,
                        uint32_t row_blocks, double *d_rows);
 int epv_reduce_rows(epv_ctx *ctx, const double *d_rows, uint64_t n_rows, uint64_t batch, int average,

@@ -285,3 +285,29 @@ def test_initialization_output_feeds_the_em_driver(tmp_path, optimize):
         assert jb.size == 0 or (jb.min() > 0 and jb.max() < tt[b])
     assert np.all(np.isfinite(host.Model.read(d + "/out.param", scale=True).rates))
     assert len(t_in.branches) == N
+
+
+def test_em_cli_failure_in_a_later_iteration_leaves_a_complete_paths_file(tmp_path):
+    """the paths file of iteration i is written by a background thread while iteration i + 1 runs;
+    when that iteration fails (here: the param file cannot be rewritten) the program must report the
+    error and exit with EXIT_FAILURE only AFTER the pending file is complete -- the synchronous
+    reference would have left a whole file behind too"""
+    model, tree, fp = simulate("tree", 60000, seed=5)
+    d = str(tmp_path)
+    open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+    _write_expected(d + "/in.paths", tree, tree.branches, fp)
+    os.mkdir(d + "/pdir")
+    link = d + "/pdir/out.param"
+    cmd = [os.path.join(BIN, "epievo_est_params_histories"), "-i", "3", "-B", "2", "-L", "1", "-s", "7",
+           "-o", d + "/out.paths", "-p", link, d + "/p.param", d + "/t.nwk", d + "/in.paths"]
+    env = dict(os.environ, EPV_TEST_FAIL_PARAM_AT="2")   # the 2nd rewrite of -p fails (test hook)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    assert r.returncode == 1, (r.returncode, r.stderr)
+    assert "bad output param file" in r.stderr
+    # the file of iteration 1 is whole: it parses, has every site of every node, and equals the
+    # oracle's paths after one iteration
+    out, names, tt = host.read_paths(d + "/out.paths")
+    assert out.n_sites == fp.n_sites and out.n_nodes == tree.n_nodes
+    m2, br, text, paths = _oracle_em(model, tree, fp, 1, 1, 2, 7, False)
+    assert orc.paths_equal(out, paths)
