@@ -11,6 +11,10 @@ size-independent properties where the oracle cannot follow in seconds:
             leaf data kept, every jump inside its branch, the same run sharded over four
             rehearsal slots is byte-identical
 
+  config 5+ 16-leaf balanced tree at n = 4.6e6 with 16 jump slots: 4.4e9 jump slots, i.e. element
+            offsets beyond 2^32 (the 64-bit index paths jump_idx / meta_idx / jbaseL of the kernels):
+            the same properties, two contexts against one
+
 The timings of these runs are kept under profiles/ by tools/full_shape_artifacts.py."""
 import os
 import subprocess
@@ -150,6 +154,68 @@ def test_config3_fused_contexts_equal_one_context_of_separate_kernels():
     assert len(g.subs) == 3 and g.phase_mode() == 3
     g.reset()
     Jg, Dg, ng = g.run_mcmc(burn, batch, seed)
+    assert ng == nacc and np.array_equal(Jg, J) and np.array_equal(Dg, D)
+    assert np.array_equal(g.tri_llh(), tri)
+    assert orc.paths_equal(g.paths(), p)
+    g.close()
+
+
+def _check_paths_are_valid(p, tree, n):
+    """every jump inside its branch, ascending inside its path"""
+    B = tree.n_nodes - 1
+    starts = p.offsets[:-1]
+    for b in range(B):
+        lo, hi = int(p.offsets[b * n]), int(p.offsets[(b + 1) * n])
+        jb = p.jumps[lo:hi]
+        if jb.size == 0:
+            continue
+        assert jb.min() > 0.0 and jb.max() < tree.branches[b + 1]
+        up = np.diff(jb) > 0.0
+        first = (starts[b * n:(b + 1) * n] - lo).astype(np.int64)      # index of each path's first jump
+        first = first[(first > 0) & (first < jb.size)]
+        up[first - 1] = True                                           # a new path may start lower
+        assert up.all()
+
+
+def test_config5_beyond_32_bit_jump_offsets():
+    """2 * 30 * 16 * n jump slots > 2^32 from n = 4.47e6 on: indices into the second path buffer of
+    the high branches no longer fit 32 bits.  ~35 GB of HBM"""
+    from epievo_amd.parallel import LocalGroup
+    from epievo_amd.sampler import DeviceSampler
+    n, burn, batch, seed, cap = 4_600_000, 1, 2, 21, 16
+    model, tree, fp = simulate("bal16", n, seed=11)
+    B = tree.n_nodes - 1
+    assert 2 * B * cap * n > 2 ** 32
+    leaves = [b for b in range(B) if tree.subtree_sizes[b + 1] == 1]
+    es0 = (fp.init.reshape(B, n) ^ (fp.counts().reshape(B, n) & 1).astype(np.uint8))[leaves]
+    d = DeviceSampler(0)
+    d.set_tree(tree); d.set_model(model); d.upload_paths(fp, cap)
+    assert d.capacity() == cap
+    d.reset()
+    tri0 = d.tri_llh()
+    J, D, nacc = d.run_mcmc(burn, batch, seed, average=False)
+    assert np.array_equal(J, np.round(J))
+    # dwell times add up: integer statistics lose at most one quantum (2^-k_b) per term
+    np.testing.assert_allclose(D.reshape(B, 8).sum(1), batch * (n - 2) * tree.branches[1:], rtol=1e-11)
+    assert 0.5 < nacc / float(batch * (n - 2)) <= 1.0
+    tri = d.tri_llh()
+    assert not np.array_equal(tri, tri0)
+    d.reset()
+    assert np.array_equal(tri, d.tri_llh())                     # reset() is idempotent on what the sweeps cached
+    p = d.paths()
+    es = (p.init.reshape(B, n) ^ (p.counts().reshape(B, n) & 1).astype(np.uint8))[leaves]
+    assert np.array_equal(es, es0)                              # the leaves keep their data
+    _check_paths_are_valid(p, tree, n)
+    # the high slots are in use: accepted proposals live in buffer 1, whose last branches start beyond 2^32
+    changed = (p.counts().reshape(B, n)[B - 1] != fp.counts().reshape(B, n)[B - 1]).sum()
+    assert changed > 1000
+    d.close()
+    del es
+    g = LocalGroup(0, 2, burn + batch)
+    g.set_tree(tree); g.set_model(model); g.upload_paths(fp, cap)
+    assert len(g.subs) == 2
+    g.reset()
+    Jg, Dg, ng = g.run_mcmc(burn, batch, seed, average=False)
     assert ng == nacc and np.array_equal(Jg, J) and np.array_equal(Dg, D)
     assert np.array_equal(g.tri_llh(), tri)
     assert orc.paths_equal(g.paths(), p)
