@@ -717,30 +717,16 @@ EPV_API int epv_set_model(epv_ctx *c, const double *triplet_rates, const double 
   return EPV_OK;
 }
 
-EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_state,
-                             const uint64_t *offsets, const double *jumps, uint32_t capacity,
-                             uint64_t global_site_offset) {
-  if (!c) return EPV_ERR_ARG;
-  if (!c->have_tree) return fail(c, EPV_ERR_STATE, "epv_set_tree must come before epv_upload_paths");
-  if (n_sites < 3 || !init_state || !offsets) return fail(c, EPV_ERR_ARG, "bad paths");
-  if (global_site_offset + n_sites > 0xffffffffull)
-    return fail(c, EPV_ERR_ARG, "site indices must fit 32 bits (Philox counter word)");
+// device storage of n_sites x B paths with `capacity` jump slots each (both buffers), the phase
+// hand-over arrays and the work lists; the paths themselves are filled in by the caller
+static int alloc_paths(epv_ctx *c, uint64_t n_sites, uint32_t capacity, uint64_t global_site_offset) {
   const uint64_t B = c->S.B, E = B * n_sites;
-  uint64_t maxj = 0;
-  for (uint64_t e = 0; e < E; ++e) {
-    if (offsets[e + 1] < offsets[e]) return fail(c, EPV_ERR_ARG, "offsets must be non-decreasing");
-    maxj = std::max<uint64_t>(maxj, offsets[e + 1] - offsets[e]);
-  }
-  if (capacity == 0) capacity = (uint32_t)std::max<uint64_t>(16u, 2u * maxj + 8u);
-  if (capacity > EPV_MAX_CAP) capacity = EPV_MAX_CAP;
-  if (maxj > capacity) return fail(c, EPV_ERR_CAPACITY, "an input path has more jumps than the capacity");
   HIP_TRY(c, hipSetDevice(c->device));
   free_paths(c);
   c->S.n = n_sites;
   c->S.g0 = global_site_offset;
   c->S.n_global = global_site_offset + n_sites;
   c->S.C = capacity;
-  c->kbar = E ? (double)offsets[E] / (double)E : 0.0;
   HIP_TRY(c, hipMalloc(&c->S.meta, 2u * E * sizeof(epv_meta_t)));
   HIP_TRY(c, hipMalloc(&c->S.jumps, 2u * E * capacity * sizeof(double)));
   HIP_TRY(c, hipMalloc(&c->S.sel, n_sites));
@@ -762,6 +748,34 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   c->S.alist_cap = ((((n_sites + 2u) / 3u + 63u) / 64u + EPV_SHARDS - 1u) / EPV_SHARDS + 1u) * 64u;
   HIP_TRY(c, hipMalloc(&c->S.alist, c->S.alist_cap * EPV_SHARDS * sizeof(uint32_t)));
   HIP_TRY(c, hipMemsetAsync(c->S.meta, 0, 2u * E * sizeof(epv_meta_t), c->stream));
+  c->first = 1;
+  c->last = n_sites - 2;
+  c->halo_mode = false;
+  c->halo_left = c->halo_right = 0;
+  c->phases_used = 0;
+  return EPV_OK;
+}
+
+EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_state,
+                             const uint64_t *offsets, const double *jumps, uint32_t capacity,
+                             uint64_t global_site_offset) {
+  if (!c) return EPV_ERR_ARG;
+  if (!c->have_tree) return fail(c, EPV_ERR_STATE, "epv_set_tree must come before epv_upload_paths");
+  if (n_sites < 3 || !init_state || !offsets) return fail(c, EPV_ERR_ARG, "bad paths");
+  if (global_site_offset + n_sites > 0xffffffffull)
+    return fail(c, EPV_ERR_ARG, "site indices must fit 32 bits (Philox counter word)");
+  const uint64_t B = c->S.B, E = B * n_sites;
+  uint64_t maxj = 0;
+  for (uint64_t e = 0; e < E; ++e) {
+    if (offsets[e + 1] < offsets[e]) return fail(c, EPV_ERR_ARG, "offsets must be non-decreasing");
+    maxj = std::max<uint64_t>(maxj, offsets[e + 1] - offsets[e]);
+  }
+  if (capacity == 0) capacity = (uint32_t)std::max<uint64_t>(16u, 2u * maxj + 8u);
+  if (capacity > EPV_MAX_CAP) capacity = EPV_MAX_CAP;
+  if (maxj > capacity) return fail(c, EPV_ERR_CAPACITY, "an input path has more jumps than the capacity");
+  int arc = alloc_paths(c, n_sites, capacity, global_site_offset);
+  if (arc) return arc;
+  c->kbar = E ? (double)offsets[E] / (double)E : 0.0;
   // staging of the CSR form
   DevTmp<uint8_t> d_init;
   DevTmp<uint64_t> d_off;
@@ -777,14 +791,87 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
                      c->S, d_init.p, d_off.p, d_j.p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->first = 1;
-  c->last = n_sites - 2;
-  c->halo_mode = false;
-  c->halo_left = c->halo_right = 0;
-  c->phases_used = 0;
   c->have_paths = true;
   c->have_reset = false;
   { int rc = plan_mh(c); return rc ? rc : plan_p2(c); }
+}
+
+// epievo_sim's forward simulation on the device (epv_forward.h): root sequence (given, or
+// EpiEvoModel::sample_state_sequence with keyed uniforms), then every branch in pre-order by
+// site-parallel thinning.  The histories end up resident like uploaded paths.
+EPV_API int epv_forward_simulate(epv_ctx *c, uint64_t n_sites, const uint8_t *root_states, uint64_t seed,
+                                 uint32_t capacity, uint64_t *total_jumps) {
+  if (!c) return EPV_ERR_ARG;
+  if (!c->have_tree || !c->have_model)
+    return fail(c, EPV_ERR_STATE, "epv_set_tree and epv_set_model must come before epv_forward_simulate");
+  if (n_sites < 3 || n_sites > 0xffffffffull) return fail(c, EPV_ERR_ARG, "bad number of sites");
+  if (capacity == 0) capacity = 16u;
+  if (capacity > EPV_MAX_CAP) capacity = EPV_MAX_CAP;
+  int rc = alloc_paths(c, n_sites, capacity, 0);
+  if (rc) return rc;
+  const uint64_t n = n_sites, N = c->S.N;
+  const uint32_t seed_lo = (uint32_t)seed, seed_hi = (uint32_t)(seed >> 32);
+  EpvFwd F{};
+  DevTmp<uint8_t> st0, st1, endv, agg, prefix;
+  DevTmp<uint32_t> k0, k1;
+  DevTmp<double> t0, t1;
+  DevTmp<unsigned long long> info;
+  HIP_TRY(c, st0.alloc(n)); HIP_TRY(c, st1.alloc(n));
+  HIP_TRY(c, k0.alloc(n)); HIP_TRY(c, k1.alloc(n));
+  HIP_TRY(c, t0.alloc(n)); HIP_TRY(c, t1.alloc(n));
+  HIP_TRY(c, endv.alloc(N * n));
+  HIP_TRY(c, info.alloc(2));
+  F.st[0] = st0.p; F.st[1] = st1.p; F.k[0] = k0.p; F.k[1] = k1.p; F.t[0] = t0.p; F.t[1] = t1.p; F.end = endv.p;
+  F.lam_max = c->model.rates[0];
+  for (int i = 1; i < 8; ++i) F.lam_max = std::max(F.lam_max, c->model.rates[i]);
+  for (int i = 0; i < 8; ++i) F.pacc[i] = c->model.rates[i] / F.lam_max;
+  if (root_states) {
+    HIP_TRY(c, hipMemcpyAsync(F.end, root_states, n, hipMemcpyHostToDevice, c->stream));
+  } else {
+    const uint64_t per_block = 256u * EPV_ROOT_PER_THREAD, nb = (n + per_block - 1u) / per_block;
+    HIP_TRY(c, agg.alloc(nb)); HIP_TRY(c, prefix.alloc(nb));
+    const double T00 = c->model.T[0], T11 = c->model.T[3], pi1 = (1.0 - T00) / (2.0 - T11 - T00);   // EpiEvoModel.cpp:289
+    hipLaunchKernelGGL(epv_fwd_root_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, n, (uint64_t)0, seed_lo, seed_hi,
+                       T00, T11, pi1, 0u, agg.p, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+    hipLaunchKernelGGL(epv_fwd_root_scan_kernel, dim3(1), dim3(64), 0, c->stream, agg.p, nb, prefix.p);
+    hipLaunchKernelGGL(epv_fwd_root_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, n, (uint64_t)0, seed_lo, seed_hi,
+                       T00, T11, pi1, 1u, agg.p, prefix.p, F.end);
+  }
+  HIP_TRY(c, hipGetLastError());
+  // tiles of EPV_FWD_THREADS sites with `halo` redundant ones on each side, `rounds` rounds a launch
+  const uint32_t halo = 16u, rounds = 64u, own_w = EPV_FWD_THREADS - 2u * halo;
+  const unsigned tiles = (unsigned)((n + own_w - 1u) / own_w);
+  unsigned long long h_info[2] = {0ull, 0ull};
+  for (uint32_t node = 1; node < N; ++node) {
+    uint32_t p = 0u;
+    hipLaunchKernelGGL(epv_fwd_begin_kernel, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, c->stream, c->S, F, node,
+                       c->parent[node], seed_lo, seed_hi, p);
+    for (uint32_t launch = 0;; ++launch) {
+      HIP_TRY(c, hipMemsetAsync(info.p, 0, 2 * sizeof(unsigned long long), c->stream));
+      hipLaunchKernelGGL(epv_fwd_rounds_kernel, dim3(tiles), dim3(EPV_FWD_THREADS), 0, c->stream, c->S, F, node,
+                         c->blen[node], seed_lo, seed_hi, p, halo, rounds, info.p);
+      HIP_TRY(c, hipGetLastError());
+      HIP_TRY(c, hipMemcpyAsync(h_info, info.p, sizeof h_info, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      p ^= 1u;
+      if (h_info[1]) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "forward simulation: %llu paths of node %u need more than %u jump slots; "
+                      "call again with a larger capacity", h_info[1], node, capacity);
+        free_paths(c);
+        return fail(c, EPV_ERR_CAPACITY, buf);
+      }
+      if (h_info[0] == 0ull) break;
+      if (launch > 100000u) { free_paths(c); return fail(c, EPV_ERR_STATE, "forward simulation does not terminate"); }
+    }
+  }
+  c->have_paths = true;
+  c->have_reset = false;
+  uint64_t tot = 0;
+  if ((rc = epv_paths_total_jumps(c, &tot))) return rc;
+  if (total_jumps) *total_jumps = tot;
+  c->kbar = (double)tot / (double)(c->S.B * n);
+  { int prc = plan_mh(c); return prc ? prc : plan_p2(c); }
 }
 
 static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base);

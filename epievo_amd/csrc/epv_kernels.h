@@ -1685,4 +1685,7 @@ __global__ void epv_unpack_columns_kernel(EpvDev S, uint64_t first, uint64_t cou
   }
 }
 
+// site-parallel forward simulation (epievo_sim's process by thinning)
+#include "epv_forward.h"
+
 #endif

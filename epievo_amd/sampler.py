@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "epv_run_mcmc_blocks", "epv_reduce_blocks", "epv_get_counters", "epv_kernel_time_ms",
     "epv_set_timing", "epv_pack_columns_dev", "epv_unpack_columns_dev", "epv_device_of",
     "epv_blocks_to_rows", "epv_reduce_rows", "epv_reduce_gathered_rows", "epv_dev_write", "epv_dev_read", "epv_set_options", "epv_get_options", "epv_phase_mode",
+    "epv_forward_simulate",
 ]
 
 
@@ -108,6 +109,8 @@ def lib():
         L.epv_reduce_gathered_rows.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u64p, C.c_uint64, C.c_int,
                                                dp, dp]
         L.epv_set_options.argtypes = [vp, C.c_uint32]
+        L.epv_forward_simulate.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32,
+                                           C.POINTER(C.c_uint64)]
         L.epv_get_options.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.epv_phase_mode.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.epv_dev_write.argtypes = [vp, vp, vp, C.c_uint64]
@@ -240,6 +243,24 @@ class DeviceSampler:
         self.n_sites = len(root)
         self._ck(self.L.epv_init_paths_indep(self.h, len(root), _p(root, C.c_uint8),
                                              _p(leaf, C.c_uint8), seed, capacity))
+
+    def forward_simulate(self, n_sites, seed, root=None, capacity=0):
+        """epievo_sim's forward simulation on the device (set_tree and set_model first); the histories
+        are resident afterwards.  Doubles the jump slots until every path fits -> total jumps"""
+        self.n_sites = int(n_sites)
+        rp = None
+        if root is not None:
+            root = np.ascontiguousarray(root, np.uint8)
+            rp = _p(root, C.c_uint8)
+        tot = C.c_uint64(0)
+        cap = capacity or 16
+        while True:
+            rc = self.L.epv_forward_simulate(self.h, self.n_sites, rp, int(seed), cap, C.byref(tot))
+            if rc == EPV_ERR_CAPACITY and cap < 2047:
+                cap = min(2047, cap * 2)
+                continue
+            self._ck(rc)
+            return int(tot.value)
 
     def indep_expectation(self, rates):
         r = np.ascontiguousarray(rates, np.float64)

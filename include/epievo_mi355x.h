@@ -132,6 +132,23 @@ int epv_phase_mode(epv_ctx *ctx, uint32_t *mode);
 int epv_init_paths_indep(epv_ctx *ctx, uint64_t n_sites, const uint8_t *root_states,
                          const uint8_t *leaf_states, uint64_t seed, uint32_t capacity);
 
+/* epievo_sim's forward simulation (src/prog/epievo_sim.cpp:102-152, 329-352 over TripletSampler,
+ * src/libepievo/TripletSampler.cpp:165-184) on the device, for the tree and model set before:
+ * the root sequence (root_states, one byte per site; NULL = EpiEvoModel::sample_state_sequence,
+ * EpiEvoModel.cpp:281-298, with keyed uniforms), then every branch in pre-order.  The reference
+ * runs ONE sequential event chain per branch; here every interior site carries its own candidate
+ * stream at the rate max_c rate_c and a candidate flips the site with probability
+ * rate[context]/max rate (thinning: the same law), candidates being resolved site-parallel in
+ * any order their nearest-neighbour dependencies allow (csrc/epv_forward.h).  The outcome is a
+ * function of `seed` alone and equals oracle/epv_oracle.c's orc_forward_thinning bit for bit; it is
+ * NOT the std::mt19937 stream of the reference (that one is restated on the host:
+ * csrc/host/epv_forward.cpp, bit-identical to the linked TripletSampler).  Afterwards the
+ * histories are resident as after epv_upload_paths (epv_download_paths brings them to the host;
+ * node states = init ^ parity of the jump count).  capacity 0 = 16 jump slots; EPV_ERR_CAPACITY
+ * when a path needs more (call again with a larger capacity: same histories). */
+int epv_forward_simulate(epv_ctx *ctx, uint64_t n_sites, const uint8_t *root_states, uint64_t seed,
+                         uint32_t capacity, uint64_t *total_jumps);
+
 /* ---- the site-independent 2-rate model of epievo_initialization (IndepSite.hpp:40-72);
  * rates = {r0, r1}; J/D laid out [(b-1)*2 + state].
  * epv_indep_expectation            expectation_sufficient_statistics (IndepSite.cpp:222-238):

@@ -1349,3 +1349,99 @@ ORC_API void orc_kat_mt_canonical(uint64_t seed, uint64_t n, double *out) {
   orc_mt19937 g; orc_mt_seed(&g, (uint32_t)seed);
   for (uint64_t i = 0; i < n; ++i) out[i] = orc_mt_canonical(&g);
 }
+
+/* ======================================================================================
+ * Forward simulation, parallel rung: what epievo_sim computes
+ * (src/prog/epievo_sim.cpp:102-152,329-352 over TripletSampler.cpp:165-184) restated as
+ * THINNING, the form the GPU generator (epievo_amd/csrc/epv_forward.h) runs site-parallel:
+ * every interior site of a branch carries a Poisson stream of candidate events at the rate
+ * lam_max = max_c rate_c (gaps -log(1 - u)/lam_max), and a candidate at time t flips its site with
+ * probability rate[context at t-]/lam_max.  Superposition + thinning give exactly the law of the
+ * reference's Gillespie loop (total rate sum_c count_c rate_c, a context drawn in proportion to
+ * count_c rate_c, a uniform site of that context).  The randomness is keyed by (seed, node, site,
+ * candidate index), so the outcome is a function of the seed alone: here the candidates of a branch
+ * are simply processed in global time order; the GPU resolves them in any order consistent with
+ * the nearest-neighbour dependencies and must produce the same bits.
+ * Root sequence: EpiEvoModel::sample_state_sequence (EpiEvoModel.cpp:281-298) with keyed uniforms.
+ * Sites 0 and n-1 never change (TripletSampler.cpp:37-70 buckets interior positions only).
+ * Returns the total number of jumps (or UINT64_MAX when jumps_cap is too small). */
+#define ORC_FWD_SWEEP 0xfffffffeu
+#define ORC_FWD_ROOT_SWEEP 0xfffffffdu
+typedef struct { double t; uint32_t site; double u; } orc_cand;
+static int cand_cmp(const void *a, const void *b) {
+  const orc_cand *x = (const orc_cand *)a, *y = (const orc_cand *)b;
+  if (x->t < y->t) return -1;
+  if (x->t > y->t) return 1;
+  return x->site < y->site ? -1 : (x->site > y->site ? 1 : 0);
+}
+ORC_API uint64_t orc_forward_thinning(const double *rates, const double *T4, int n_nodes, const uint32_t *parent,
+                                      const double *blen, uint64_t n_sites, uint64_t seed, const uint8_t *root_in,
+                                      uint8_t *init_out, uint64_t *offsets_out, double *jumps_out, uint64_t jumps_cap,
+                                      uint8_t *states_out /* [n_nodes][n_sites] end states, may be NULL */) {
+  const size_t n = (size_t)n_sites;
+  uint8_t *end = (uint8_t *)malloc((size_t)n_nodes * n);
+  double d[2];
+  if (root_in) {
+    memcpy(end, root_in, n);
+  } else {
+    const double pi1 = (1.0 - T4[0]) / (2.0 - T4[3] - T4[0]);
+    orc_keyed_block(seed, 0u, ORC_FWD_ROOT_SWEEP, 0, 0, 0, 0, d);
+    end[0] = d[0] < pi1;
+    for (size_t i = 1; i < n; ++i) {
+      orc_keyed_block(seed, (uint32_t)i, ORC_FWD_ROOT_SWEEP, 0, 0, 0, 0, d);
+      const double p = end[i - 1] ? T4[3] : T4[0];
+      end[i] = (d[0] <= p) ? end[i - 1] : (uint8_t)!end[i - 1];
+    }
+  }
+  double lam_max = rates[0];
+  for (int c = 1; c < 8; ++c) if (rates[c] > lam_max) lam_max = rates[c];
+  double pacc[8];
+  for (int c = 0; c < 8; ++c) pacc[c] = rates[c] / lam_max;
+  uint64_t total = 0;
+  size_t cap = 1024, cnt = 0;
+  orc_cand *cand = (orc_cand *)malloc(cap * sizeof(orc_cand));
+  uint32_t *per_site = (uint32_t *)malloc(n * sizeof(uint32_t));
+  double **sj = (double **)calloc(n, sizeof(double *));
+  int ok = 1;
+  for (int node = 1; node < n_nodes && ok; ++node) {
+    uint8_t *st = end + (size_t)node * n;
+    memcpy(st, end + (size_t)parent[node] * n, n);
+    memcpy(init_out + (size_t)(node - 1) * n, st, n);
+    cnt = 0;
+    for (size_t s = 1; s + 1 < n; ++s) {
+      double t = 0.0;
+      for (uint32_t k = 0;; ++k) {
+        orc_keyed_block(seed, (uint32_t)s, ORC_FWD_SWEEP, (uint32_t)node, 0, k, 0, d);
+        t += -orc_log(1.0 - d[0]) / lam_max;
+        if (!(t < blen[node])) break;
+        if (cnt == cap) { cap *= 2; cand = (orc_cand *)realloc(cand, cap * sizeof(orc_cand)); }
+        cand[cnt].t = t; cand[cnt].site = (uint32_t)s; cand[cnt].u = d[1];
+        ++cnt;
+      }
+    }
+    qsort(cand, cnt, sizeof(orc_cand), cand_cmp);
+    memset(per_site, 0, n * sizeof(uint32_t));
+    /* two passes: count the accepted flips of every site, then lay them out site by site */
+    uint8_t *work = (uint8_t *)malloc(n);
+    memcpy(work, st, n);
+    uint8_t *acc = (uint8_t *)malloc(cnt ? cnt : 1);
+    for (size_t i = 0; i < cnt; ++i) {
+      const size_t s = cand[i].site;
+      const int ctx = 4 * work[s - 1] + 2 * work[s] + work[s + 1];
+      acc[i] = cand[i].u < pacc[ctx];
+      if (acc[i]) { work[s] ^= 1; ++per_site[s]; }
+    }
+    uint64_t *off = offsets_out + (size_t)(node - 1) * n;
+    for (size_t s = 0; s < n; ++s) { off[s] = total; total += per_site[s]; }
+    if (total > jumps_cap) { ok = 0; free(work); free(acc); break; }
+    memset(per_site, 0, n * sizeof(uint32_t));
+    for (size_t i = 0; i < cnt; ++i)
+      if (acc[i]) { const size_t s = cand[i].site; jumps_out[off[s] + per_site[s]++] = cand[i].t; }
+    memcpy(st, work, n);
+    free(work); free(acc);
+  }
+  offsets_out[(size_t)(n_nodes - 1) * n] = total;
+  if (states_out && ok) memcpy(states_out, end, (size_t)n_nodes * n);
+  free(cand); free(per_site); free(sj); free(end);
+  return ok ? total : UINT64_MAX;
+}

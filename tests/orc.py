@@ -89,6 +89,9 @@ def orc_lib():
         L.orc_kat_end_cond_paths.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_int,
                                              C.c_double, C.c_uint64, C.POINTER(C.c_uint32), dp, C.c_uint64]
         L.orc_set_sampler.argtypes = [C.c_void_p, C.c_int]
+        L.orc_forward_thinning.argtypes = [dp, dp, C.c_int, u32p, dp, C.c_uint64, C.c_uint64, u8p, u8p, u64p, dp,
+                                           C.c_uint64, u8p]
+        L.orc_forward_thinning.restype = C.c_uint64
         L.orc_kat_exp.argtypes = [C.c_double]
         L.orc_kat_exp.restype = C.c_double
         L.orc_kat_log.argtypes = [C.c_double]
@@ -352,3 +355,26 @@ def init_paths_indep(engine, seed, rates, root, leaf, T, rung="B"):
                                              _p(jumps, C.c_double), cap)
     assert tot <= cap
     return FlatPaths(n, 2, init, off, jumps[:tot])
+
+
+def forward_thinning(model, tree, n, seed, root=None):
+    """the forward simulator's parallel rung on the CPU (thinning with keyed randomness, candidates in
+    global time order) -> (FlatPaths, states[n_nodes][n])"""
+    from epievo_amd.host import FlatPaths
+    B = tree.n_nodes - 1
+    init, off = np.zeros(B * n, np.uint8), np.zeros(B * n + 1, np.uint64)
+    states = np.zeros((tree.n_nodes, n), np.uint8)
+    rp = None
+    if root is not None:
+        root = np.ascontiguousarray(root, np.uint8)
+        rp = _p(root, C.c_uint8)
+    cap = max(1024, int(4 * n * B * (0.5 + tree.branches[1:].max() * model.rates.max())))
+    while True:
+        jumps = np.zeros(cap)
+        tot = orc_lib().orc_forward_thinning(_p(model.rates, C.c_double), _p(model.T, C.c_double), tree.n_nodes,
+                                             _p(tree.parent_ids, C.c_uint32), _p(tree.branches, C.c_double), n, seed, rp,
+                                             _p(init, C.c_uint8), _p(off, C.c_uint64), _p(jumps, C.c_double), cap,
+                                             _p(states, C.c_uint8))
+        if tot != 2 ** 64 - 1:
+            return FlatPaths(n, tree.n_nodes, init, off, jumps[:tot]), states
+        cap *= 4
