@@ -283,6 +283,7 @@ def main():
         if args.driver == "cpp":
             # control plane only (the id broadcast, barriers, the max over ranks): the data plane is
             # RCCL inside libepv_rccl.so, through the communicator the C++ driver makes
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)   # (fewer GPUs than ranks: a rehearsal)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
         elif args.backend == "nccl":
@@ -295,8 +296,28 @@ def main():
 
     model = ref_test_model()
     tree = config(args.config)
+    fallback = None
     if args.driver == "cpp":
-        eng = CppEngine(args, model, tree, world, rank, local_rank, dist)
+        try:
+            eng, err = CppEngine(args, model, tree, world, rank, local_rank, dist), None
+        except Exception as e:      # e.g. RCCL cannot form the communicator (two ranks on one GPU)
+            eng, err = None, "%s: %s" % (type(e).__name__, e)
+        if dist is not None:
+            # the ranks agree: either all run the C++ driver or all switch to the Python one, whose
+            # exchanges then go over the control-plane group (gloo: device buffers bounced through the host)
+            bad = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()):
+                errs = [None] * world
+                dist.all_gather_object(errs, err)
+                fallback = "C++ driver unavailable on this launch (%s); ran the Python driver over gloo" % \
+                           next(e for e in errs if e)
+                eng = None
+        elif err is not None:
+            raise RuntimeError(err)
+        if eng is None:
+            args.backend = "gloo"
+            eng = TorchEngine(args, model, tree, world, rank, local_rank, dist, torch)
     else:
         eng = TorchEngine(args, model, tree, world, rank, local_rank, dist, torch)
     n_gpus, n_global, n_local = eng.n_gpus, eng.n_global, args.sites
@@ -419,7 +440,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "sites_per_gpu": n_local, "sites_total": n_global, "branches": B,
                        "burn_in": BURN_IN, "batch": BATCH, "mean_jumps_per_path": kbar, "shards_per_gpu": k_eff,
-                       "driver": eng.describe(), "transport": eng.transport,
+                       "driver": eng.describe() + ("; " + fallback if fallback else ""), "transport": eng.transport,
                        "launch": ("torch.distributed.run, one rank per GPU" if dist is not None
                                   else "one process drives every GPU"),
                        "sharding": "contiguous site shards cut on 16384-site rows, %d-column redundant halos "
