@@ -36,7 +36,7 @@ int main(int argc, const char **argv) {
   try {
     bool VERBOSE = false, single_branch = false, optimize_branches = false;
     string outfile, param_file_updated, tree_file, treefile_updated, gpu_list;
-    size_t iteration = 10, batch = 10, burnin = 10;
+    size_t iteration = 10, batch = 10, burnin = 10, paths_every = 1;
     size_t rng_seed = std::numeric_limits<size_t>::max();
     static const double param_tol = 1e-10;
 
@@ -54,8 +54,14 @@ int main(int argc, const char **argv) {
     opt_parse.add_opt("verbose", 'v', "print more run info", false, VERBOSE);
     opt_parse.add_opt("gpus", 'g', "GPUs to shard the sites over: all | 0,1,.. (default: EPV_DEVICES or 0)", false,
                       gpu_list);
+    // extension: the reference rewrites the whole paths file after EVERY iteration (:280-283; the file
+    // doubles as a checkpoint).  -e k keeps that for every k-th iteration and the last one: the final
+    // file is the same bytes, the ones in between are not written
+    opt_parse.add_opt("paths-every", 'e', "write the paths file every k-th iteration and after the last (default 1: "
+                      "every iteration, as the reference does)", false, paths_every);
     vector<string> leftover_args;
     opt_parse.parse(argc, argv, leftover_args);
+    if (paths_every == 0) paths_every = 1;
     if (argc == 1 || opt_parse.help_requested()) {
       cerr << opt_parse.help_message() << endl << opt_parse.about_message() << endl;
       return EXIT_SUCCESS;
@@ -186,6 +192,14 @@ int main(int argc, const char **argv) {
         if (fail_at && (size_t)std::atol(fail_at) == itr + 1) out_param.setstate(std::ios::failbit);
         if (!out_param) throw std::runtime_error("bad output param file: " + param_file_updated);
         out_param << the_model.format_for_param_file() << endl;
+      }
+      if ((itr + 1) % paths_every != 0 && itr + 1 != iteration) {
+        if (optimize_branches && !treefile_updated.empty()) {
+          std::ofstream out_tree(treefile_updated);
+          if (!out_tree) throw std::runtime_error("bad output param file: " + treefile_updated);
+          out_tree << th.newick() << endl;
+        }
+        continue;
       }
       t0 = now();
       if (writer.joinable()) writer.join();

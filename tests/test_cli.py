@@ -311,3 +311,22 @@ def test_em_cli_failure_in_a_later_iteration_leaves_a_complete_paths_file(tmp_pa
     assert out.n_sites == fp.n_sites and out.n_nodes == tree.n_nodes
     m2, br, text, paths = _oracle_em(model, tree, fp, 1, 1, 2, 7, False)
     assert orc.paths_equal(out, paths)
+
+
+def test_em_cli_paths_every_k_leaves_the_same_final_files(tmp_path):
+    """-e k (extension): the paths file is rewritten every k-th iteration and after the last one
+    instead of after every iteration -- the final paths, parameters and -v lines are the same"""
+    model, tree, fp = simulate("tree", 3000, seed=13)
+    d = str(tmp_path)
+    open(d + "/p.param", "w").write(TEST_PARAM_TEXT)
+    open(d + "/t.nwk", "w").write(TREE_NWK_TEXT)
+    _write_expected(d + "/in.paths", tree, tree.branches, fp)
+    outs = {}
+    for tag, extra in (("every", []), ("third", ["-e", "3"]), ("last", ["-e", "100"])):
+        r = subprocess.run([os.path.join(BIN, "epievo_est_params_histories"), "-i", "5", "-B", "2", "-L", "1", "-s", "3", "-b",
+                            "-o", d + "/%s.paths" % tag, "-p", d + "/%s.param" % tag, "-t", d + "/%s.nwk" % tag, "-v"] + extra +
+                           [d + "/p.param", d + "/t.nwk", d + "/in.paths"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = (open(d + "/%s.paths" % tag, "rb").read(), open(d + "/%s.param" % tag).read(),
+                     open(d + "/%s.nwk" % tag).read(), [l for l in r.stderr.split("\n") if l and l[0].isdigit()])
+    assert outs["every"] == outs["third"] == outs["last"]

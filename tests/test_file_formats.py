@@ -224,3 +224,34 @@ def test_newick_parse_and_print_against_the_reference(tmp_path, text):
     own = C.create_string_buffer(1 << 14)
     assert L.epvh_tree_newick(p.encode(), own, len(own)) == 0
     assert own.value == out.value
+
+
+def test_local_paths_io_on_several_threads_is_the_sequential_io(tmp_path, monkeypatch):
+    """files of 65536 rows or more are parsed / formatted in pieces on all host cores (pread / pwrite at
+    the pieces' offsets): the same bytes and the same arrays as one thread, and as the reference"""
+    model, tree, fp = simulate("tree", 70001, seed=8)
+    d = str(tmp_path)
+    monkeypatch.setenv("EPV_IO_THREADS", "1")
+    host.write_paths(d + "/one.paths", tree.node_names, tree.branches, fp)
+    one, names1, tt1 = host.read_paths(d + "/one.paths")
+    for threads in ("3", "8"):
+        monkeypatch.setenv("EPV_IO_THREADS", threads)
+        host.write_paths(d + "/many.paths", tree.node_names, tree.branches, fp)
+        assert open(d + "/many.paths", "rb").read() == open(d + "/one.paths", "rb").read()
+        many, names, tt = host.read_paths(d + "/one.paths")
+        assert names == names1 == tree.node_names and np.array_equal(tt, tt1)
+        assert orc.paths_equal(many, one) and orc.paths_equal(many, fp)
+    if orc.have_ref():
+        ref_write_paths(d + "/ref.paths", tree, tree.branches, fp)
+        assert open(d + "/ref.paths", "rb").read() == open(d + "/one.paths", "rb").read()
+    # rows that take the reader's slow path inside a piece: blank lines, spaces, a row per node whose
+    # tot_time is spelled differently (same value)
+    txt = open(d + "/one.paths").read().split("\n")
+    k = len(txt) // 2 + 7
+    assert not txt[k].startswith("NODE")
+    site, st, ttok, rest = txt[k].split("\t", 3)
+    txt[k] = "%s %s\t%s0\t%s" % (site, st, ttok, rest) if "." in ttok else txt[k]
+    txt.insert(k, "")
+    open(d + "/odd.paths", "w").write("\n".join(txt))
+    odd, _, _ = host.read_paths(d + "/odd.paths")
+    assert orc.paths_equal(odd, fp)
