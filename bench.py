@@ -388,12 +388,15 @@ def main():
         if os.path.exists(tj):
             try:
                 tq = json.load(open(tj)).get(args.config, {})
-                traffic = tq.get("hbm_bytes_per_launch")
+                # FETCH_SIZE reads half the bytes of the 128-B lines a kernel touches on gfx950, for every
+                # access width and stride of these kernels (profiles/r03_fetch_calibration.txt): doubled
+                traffic = tq.get("hbm_bytes_per_launch_fetch_x2")
                 if traffic is not None:
                     # a citation, not this run's counters: PMC passes cannot run next to the timed region
                     traffic_source = ("profiles/%s_pmc_hbm_%s.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                      "passes, one context per GPU; committed file, not measured in this run)"
-                                      % (tq.get("round", "?"), args.config))
+                                      "passes, one context per GPU; 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction "
+                                      "calibrated on this kernel's access patterns in profiles/r03_fetch_calibration.txt; "
+                                      "committed file, not measured in this run)" % (tq.get("round", "?"), args.config))
             except Exception:
                 traffic = None
         # what really bounds these kernels: VALU issue.  Instruction counts per launch come from

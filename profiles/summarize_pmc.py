@@ -5,11 +5,13 @@ launch, and write profiles/traffic.json for bench.py's roofline.traffic field.
 
   python profiles/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <config> <round-tag>
 
-Units: FETCH_SIZE / WRITE_SIZE are KiB.  On gfx950 FETCH_SIZE reads half the bytes of a
-WIDE (16 B/lane) coalesced stream; this sampler's loads are 1-byte and 8-byte per lane,
-an uncalibrated width, so the raw value is reported and the x2-corrected read side is
-kept alongside as an upper bound.  WRITE_SIZE was checked on epv_reset_kernel, which
-writes exactly n*8 bytes of tri: 7812.5 KiB for n = 1e6, i.e. exact.
+Units: FETCH_SIZE / WRITE_SIZE are KiB.  On gfx950 FETCH_SIZE reads HALF the bytes of the
+128-byte lines a kernel touches -- calibrated for this sampler's own access patterns (2- and
+8-byte loads per lane, unit stride, every third element, one lane in sixteen) by
+tools/fetch_calib.hip: profiles/r03_fetch_calibration.txt, ratio 0.500 in every case -- so the
+read side is doubled (hbm_bytes_per_launch_fetch_x2 is the figure bench.py cites; the raw sum is
+kept beside it).  WRITE_SIZE was checked on epv_reset_kernel, which writes exactly n*8 bytes of
+tri: 7812.5 KiB for n = 1e6, i.e. exact.
 """
 import collections
 import csv
