@@ -421,7 +421,15 @@ def main():
                              "profiled_phase_mode": q.get("phase_mode")}
             except Exception:
                 issue = None
-        achieved_device = achieved * k_eff
+        # how many colour-phase launches were really in flight together: the time the timed launches
+        # took, scaled to all phase launches of the timed region, over its wall clock (the k_eff
+        # contexts of a GPU never overlap perfectly; the statistics kernels share the device too)
+        phase_launches_per_gpu = float(args.steps) * (BURN_IN + BATCH) * 3 * k_eff
+        overlap = min(float(k_eff), avg_ms * 1e-3 * phase_launches_per_gpu / el) if avg_ms > 0 else float(k_eff)
+        achieved_device = achieved * overlap
+        if issue is not None:
+            issue["measured_overlap"] = overlap
+            issue["frac"] = overlap * issue["bound_ms_per_launch"] / avg_ms
         from epievo_amd.sampler import DeviceSampler
         phase_mode = eng.phase_mode()
         phase_kernels = DeviceSampler.PHASE_KERNELS[phase_mode]
@@ -449,14 +457,15 @@ def main():
                        "sharding": "contiguous site shards cut on 16384-site rows, %d-column redundant halos "
                                    "refreshed once per step, one all-gather of integer J/D rows per step; "
                                    "%d GPU shard(s) x %d concurrent context(s) per GPU" % (eng.halo, n_gpus, k_eff)},
-            # frac = what the DEVICE sustains: k_eff launches (one per context of this GPU) run
-            # concurrently, each timed with its own HIP events on its own stream
+            # frac = what the DEVICE sustains: up to k_eff launches (one per context of this GPU) run
+            # concurrently, each timed with its own HIP events on its own stream; achieved = the
+            # per-launch rate x the MEASURED overlap of those launches
             "roofline": {"bound": "hbm", "kernel": phase_kernels + " (one colour phase of one context = one timed launch group)",
                          "achieved": achieved_device,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_device / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "bytes_per_resample": bytes_per,
                          "resamples_per_launch": per_launch_units, "avg_launch_ms": avg_ms,
-                         "launches_timed": n_launch, "concurrent_launches": k_eff,
+                         "launches_timed": n_launch, "concurrent_launches": k_eff, "measured_overlap": overlap,
                          "achieved_per_launch": achieved, "phase_mode": phase_mode, "issue": issue},
         }
         out["config"]["proposal_ratio"] = (

@@ -201,7 +201,7 @@ int plan_p2(epv_ctx *c) {
   const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
   const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * 6u * 8u;     // constants, matrix table: once per block
   const size_t per_wave_fixed = ((((size_t)N * 64u + 1u) / 2u + 1u) & ~(size_t)1u) * 8u +
-                                (3u * (size_t)B * 64u * sizeof(epv_meta_t) + 15u) / 16u * 16u;   // node table, meta cache
+                                ((3u * 64u + 2u) * (size_t)B * sizeof(epv_meta_t) + 15u) / 16u * 16u;   // node table, meta cache (+ 2 edge columns)
   const size_t fixed = shared + per_wave_fixed;
   // one lane's worst case: every branch with 2C+1 segments (records K+1, heavy K)
   const uint64_t worst_rec = (uint64_t)B * (2u * C + 2u), worst_heavy = (uint64_t)B * (2u * C + 1u);

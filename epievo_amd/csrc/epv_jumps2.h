@@ -216,19 +216,22 @@ __device__ __forceinline__ bool epv_seg_search_grouped(const EpvDev &S, const do
 }
 
 // one dirty branch (task word bt, its segments at segs/outs[first ..]): results in order into the
-// proposal; a capacity overflow flags the site (phase index tid)
+// proposal; a capacity overflow flags the site (phase index tid).  The task word carries the
+// proposal's buffer and the branch's start state (bits 61, 60) so that the lane's chain does not
+// begin with two dependent loads (sel, then the meta word the proposal kernel wrote)
 __device__ __forceinline__ void epv_seg_assemble_one(const EpvDev &S, const double *s_rates, const EpvSegTask *segs,
                                                      const EpvSegOut *outs, unsigned long long bt, uint64_t first,
                                                      uint64_t s0, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
-                                                     bool nielsen) {
+                                                     bool nielsen, uint32_t *node_table = nullptr, uint64_t site_lane0 = 0) {
+  // node_table (fused phase): the wave's LDS table [node][lane]; the branch's jump count goes into
+  // bits 14..24 of its owner's entry, where the acceptance stage picks it up
   const uint64_t n = S.n;
   const uint32_t B = S.B, C = S.C;
   const uint64_t site = bt & 0xffffffffffull;
   const uint32_t b = (uint32_t)(bt >> 40) & 4095u, nds = (uint32_t)(bt >> 52) & 127u, end_state = (uint32_t)(bt >> 59) & 1u;
-  const uint32_t selP = S.sel[site] ^ 1u;
+  const uint32_t start_state = (uint32_t)(bt >> 60) & 1u, selP = (uint32_t)(bt >> 61) & 1u;
   epv_meta_t *meta = S.meta + meta_idx(S, selP, b, site);
   double *dst = S.jumps + jump_idx(S, selP, b, site);
-  const uint32_t start_state = (uint32_t)(*meta >> EPV_INIT_SHIFT);
   uint32_t cnt = 0;
   bool ovf = false;
   for (uint32_t q = 0; q < nds && !ovf; ++q) {
@@ -258,6 +261,10 @@ __device__ __forceinline__ void epv_seg_assemble_one(const EpvDev &S, const doub
     S.prop_flag[(site - s0) / 3u] = 1u;
   }
   *meta = (epv_meta_t)((start_state << EPV_INIT_SHIFT) | cnt);
+  if (node_table) {
+    uint32_t *e = node_table + (b + 1u) * 64u + (uint32_t)((site - site_lane0) / 3u);
+    *e = (*e & ~(0x7ffu << 14)) | (cnt << 14);
+  }
 }
 
 // one lane per dirty branch: the results of its dirty segments, in order, into the proposal

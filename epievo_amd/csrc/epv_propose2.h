@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
   const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
   const uint32_t tab_dbl = S.B * 4u * EPV_SEGTAB_DBL;
   const uint32_t regA_dbl = ((S.N * 64u + 1u) / 2u + 1u) & ~1u;
-  const uint32_t mc_dbl = (3u * S.B * 64u * (uint32_t)sizeof(epv_meta_t) + 15u) / 16u * 2u;   // meta words of the three columns
+  // meta words of the three columns of every lane, + the column two sites left of lane 0 and two
+  // sites right of the last lane (the acceptance stage's outer triples; the other lanes' outer
+  // columns ARE their neighbour lanes' inner ones: lane l + 1 sits three sites further)
+  const uint32_t mc_dbl = ((3u * 64u + 2u) * S.B * (uint32_t)sizeof(epv_meta_t) + 15u) / 16u * 2u;
   // a block holds blockDim.x / 64 waves: constants and the matrix table once, then per wave the
   // node table, the meta cache and the pool
   const uint32_t wave_id = threadIdx.x >> 6;
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
   // batch of independent loads; the four passes below then read LDS instead of paying a global
   // round trip per branch (the kernel is bound by memory latency, not by issue)
   epv_meta_t *s_meta = reinterpret_cast<epv_meta_t *>(s_wave + regA_dbl);
+  epv_meta_t *s_edge = s_meta + 3u * S.B * 64u;     // [0 .. B): left of lane 0, [B .. 2B): right of the last valid lane
   const int lane = epv_lane();
   // GPOOL: rows of 64 interleaved records (row r of lane l at (r * 64 + l) * 2 doubles), then
   // the flat heavy list; LDS: records packed by a wave prefix sum, the heavy list behind them
@@ -236,6 +240,16 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
     }
   }
 
+  // FUSED: the two outer columns no neighbour lane holds
+  const unsigned long long vmask = __ballot(valid);
+  const int last_lane = vmask ? 63 - __clzll((long long)vmask) : 0;
+  if (FUSED && valid && (lane == 0 || lane == last_lane)) {
+    const bool hasLL = S.g0 + site > 1u, hasRR = S.g0 + site < S.n_global - 2u;
+    for (uint32_t b = 0; b < B; ++b) {
+      if (lane == 0) s_edge[b] = hasLL ? S.meta[(selLL ? Bn : 0ull) + (uint64_t)b * n + (site - 2)] : (epv_meta_t)0;
+      if (lane == last_lane) s_edge[B + b] = hasRR ? S.meta[(selRR ? Bn : 0ull) + (uint64_t)b * n + (site + 2)] : (epv_meta_t)0;
+    }
+  }
   P2_MARK(0);
   // FUSED: lengths of the wave's private lists (wave-uniform), and which lanes' sites await acceptance
   uint32_t f_nseg = 0u, f_nbt = 0u;
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
           n1 = leaf_state ? 1.0 : 0.0;
         } else {
           for (uint32_t ch = 1u; ch < sub; ch += S.subtree[node + ch]) {
-            const double *a = my + (size_t)(regA[(node + ch) * 64u + lane] & 0x7fffffffu) * RS;
+            const double *a = my + (size_t)(regA[(node + ch) * 64u + lane] & 0x3fffffffu) * RS;
             n0 *= a[0];   // p.front() of the child's branch
             n1 *= a[1];
           }
@@ -459,14 +473,16 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
           nds += seg_clean ? 0u : 1u;
           word |= (unsigned long long)sampled << (k & 63u);
           if (k < 64u) w64 = word;
-          if ((k & 63u) == 63u) { states[k >> 6] = word; word = 0ull; }
+          if (!FUSED && (k & 63u) == 63u) { states[k >> 6] = word; word = 0ull; }   // (the fused phase hands the states over in its segment tasks)
           prev = sampled;
           pk0 = nxt0; pk1 = nxt1;
         }
         hrec0 = hcur;
         if (K >= 2u) hcur += K;
-        if ((K & 63u) && !clean) states[(K - 1u) >> 6] = word;   // only a dirty branch is read back
-        regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children
+        if (!FUSED && (K & 63u) && !clean) states[(K - 1u) >> 6] = word;   // only a dirty branch is read back
+        // proposal end state for the children (bit 31), start state (bit 30); bits 14..24 take the
+        // jump count when the fused phase has assembled the branch
+        regA[node * 64u + lane] = off | (prev << 31) | (start_state << 30);
         // same as the current path?  (no jumps on either, same start state)
         ident = ident && clean && mM == (start_state << EPV_INIT_SHIFT);
         dirty_b = !clean;
@@ -503,7 +519,8 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
             uint32_t *bfl = FUSED ? F.bfirst + f_wave * F.bt_cap : S.bfirst + (uint64_t)shard * S.btask_cap;
             const uint64_t seg_room = FUSED ? F.seg_cap : S.seg_cap, bt_room = FUSED ? F.bt_cap : S.btask_cap;
             if (i0 + nds <= seg_room && j0 < bt_room) {
-              btl[j0] = site | ((unsigned long long)b << 40) | ((unsigned long long)nds << 52) | ((unsigned long long)end_b << 59);
+              btl[j0] = site | ((unsigned long long)b << 40) | ((unsigned long long)nds << 52) | ((unsigned long long)end_b << 59) |
+                        ((unsigned long long)st_b << 60) | ((unsigned long long)(selM ^ 1u) << 61);
               bfl[j0] = (uint32_t)i0;
               uint32_t prev = st_b;
               double tp = 0.0;     // running sum of the segment lengths (SingleSiteSampler.cpp:218)
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       P2_MARK(7);
       for (uint32_t i = (uint32_t)lane; i < (EPV_DBG_SKIP < 2 ? f_nbt : 0u); i += 64u)
         epv_seg_assemble_one(S, s_rates, segs, outs, F.bt[f_wave * F.bt_cap + i], F.bfirst[f_wave * F.bt_cap + i], s0,
-                             seed_lo, seed_hi, sweep, nielsen);
+                             seed_lo, seed_hi, sweep, nielsen, regA, site - 3u * (uint64_t)lane);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
       P2_MARK(8);
@@ -668,6 +685,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
           const uint64_t c = osite - 1u + (uint64_t)w;            // centre column of this triple
           // buffers of the three columns (bits 8.. of the owner's word: LL, L, proposal, R, RR)
           const uint32_t bl = (ow >> (8u + w)) & 1u, bm = (ow >> (9u + w)) & 1u, br = (ow >> (10u + w)) & 1u;
+#ifdef EPV_ACC_GLOBAL_META
           if (F.meta_cache) {
             const uint32_t B2 = S.B;
 #pragma unroll 4
@@ -679,6 +697,27 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
               mc[(1u * B2 + b) * 64u] = m1;
               mc[(2u * B2 + b) * 64u] = m2;
             }
+#else
+          if (F.meta_cache) {
+            // the meta words of the triple's columns without a global round trip: the neighbours'
+            // current paths were staged at the head of the kernel (they belong to other colours and
+            // do not change in this phase), the proposal's are the start states of the node table
+            // and the counts the assembly left there
+            const uint32_t B2 = S.B;
+#pragma unroll 4
+            for (uint32_t b = 0; b < B2; ++b) {
+              const uint32_t ra = regA[(b + 1u) * 64u + o];
+              const epv_meta_t mP = (epv_meta_t)((((ra >> 30) & 1u) << EPV_INIT_SHIFT) | ((ra >> 14) & 0x7ffu));
+              const epv_meta_t mL = s_meta[(0u * B2 + b) * 64u + o], mR = s_meta[(1u * B2 + b) * 64u + o];
+              epv_meta_t m0, m1, m2;
+              if (w == 0u) { m0 = o > 0u ? s_meta[(1u * B2 + b) * 64u + (o - 1u)] : s_edge[b]; m1 = mL; m2 = mP; }
+              else if (w == 1u) { m0 = mL; m1 = mP; m2 = mR; }
+              else { m0 = mP; m1 = mR; m2 = o < (uint32_t)last_lane ? s_meta[(0u * B2 + b) * 64u + (o + 1u)] : s_edge[B2 + b]; }
+              mc[(0u * B2 + b) * 64u] = m0;
+              mc[(1u * B2 + b) * 64u] = m1;
+              mc[(2u * B2 + b) * 64u] = m2;
+            }
+#endif
             v = triple_llh_cached(S, s_const, s_blen, mc, 64u, 0u, bl, c - 1u, 1u, bm, c, 2u, br, c + 1u, A);
           } else {
             v = triple_llh(S, s_const, s_blen, bl, c - 1u, bm, c, br, c + 1u, A);

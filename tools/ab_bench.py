@@ -19,7 +19,7 @@ for rep in range(a.reps):
         env = dict(os.environ, EPIEVO_MI355X_LIB=lib)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
                             "--no-cpu-baseline", "--no-reference-leg", "--config", a.config, "--sites", str(a.sites),
-                            "--shards-per-gpu", str(a.shards_per_gpu)], env=env, capture_output=True, text=True)
+                            "--shards-per-gpu", str(a.shards_per_gpu), "--driver", "torch"], env=env, capture_output=True, text=True)
         try:
             j = json.loads(r.stdout.strip().split("\n")[-1])
             print("%-10s %s n=%d k=%d  %.4e resamples/s  %.2f ms/step  launch %.4f ms" %

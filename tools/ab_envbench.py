@@ -9,6 +9,7 @@ ap.add_argument("--config", default="tree")
 ap.add_argument("--sites", type=int, default=1000000)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--shards-per-gpu", type=int, default=2)
+ap.add_argument("--extra", default="", help="extra bench.py arguments")
 ap.add_argument("specs", nargs="+")
 a = ap.parse_args()
 for rep in range(a.reps):
@@ -20,7 +21,7 @@ for rep in range(a.reps):
             env[k] = v
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
                             "--no-cpu-baseline", "--no-reference-leg", "--config", a.config, "--sites", str(a.sites),
-                            "--shards-per-gpu", str(a.shards_per_gpu)], env=env, capture_output=True, text=True)
+                            "--shards-per-gpu", str(a.shards_per_gpu)] + a.extra.split(), env=env, capture_output=True, text=True)
         try:
             j = json.loads(r.stdout.strip().split("\n")[-1])
             print("%-12s %s n=%d k=%d  %.4e resamples/s  %.2f ms/step  launch %.4f ms" %

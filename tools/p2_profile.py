@@ -1,8 +1,8 @@
 """wave-time per section of epv_mh_propose2_kernel (build_ab/libepv_prof.so: tools/ab_defs.py build
 "prof=-DEPV_P2_PROFILE").  python tools/p2_profile.py [sites] [config]"""
 import sys, os, ctypes as C
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
-os.environ.setdefault("EPIEVO_MI355X_LIB", "/root/repo/build_ab/libepv_prof.so")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
+os.environ.setdefault("EPIEVO_MI355X_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'build_ab', 'libepv_prof.so'))
 from epievo_amd.workloads import simulate
 from epievo_amd.sampler import DeviceSampler, lib
 N_SITES = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
