@@ -467,7 +467,8 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     ++c->ev_used;
     HIP_TRY(c, hipEventRecord(e0, c->stream));
   }
-  const bool refq = c->S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO;
+  // (root resampling changes the proposal's normalising constant with the path: the ratio must be evaluated)
+  const bool refq = c->S.flags & (EPV_FLAG_REFERENCE_PROPOSAL_RATIO | EPV_FLAG_SAMPLE_ROOT);
   // the reference-arithmetic mode keeps the first kernel, and so do trees whose record pool does
   // not fit LDS: with the pool in global memory the second kernel's extra passes over it cost
   // more than its dense evaluation saves (16-leaf tree: 830 vs 676 us);
@@ -878,13 +879,11 @@ static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base);
 
 EPV_API int epv_set_options(epv_ctx *c, uint32_t flags) {
   if (!c) return EPV_ERR_ARG;
-  if (flags & EPV_OPT_SAMPLE_ROOT)
-    return fail(c, EPV_ERR_ARG, "EPV_OPT_SAMPLE_ROOT (SingleSiteSampler::SAMPLE_ROOT = true) is not supported: "
-                                "the kernels keep the root state, as every program of the reference does");
-  if (flags & ~(uint32_t)(EPV_OPT_REFERENCE_PROPOSAL_RATIO | EPV_OPT_FORWARD_REJECTION))
+  if (flags & ~(uint32_t)(EPV_OPT_REFERENCE_PROPOSAL_RATIO | EPV_OPT_FORWARD_REJECTION | EPV_OPT_SAMPLE_ROOT))
     return fail(c, EPV_ERR_ARG, "unknown option bits");
   static_assert(EPV_OPT_REFERENCE_PROPOSAL_RATIO == EPV_FLAG_REFERENCE_PROPOSAL_RATIO &&
-                EPV_OPT_FORWARD_REJECTION == EPV_FLAG_FORWARD_REJECTION, "option bits");
+                EPV_OPT_FORWARD_REJECTION == EPV_FLAG_FORWARD_REJECTION && EPV_OPT_SAMPLE_ROOT == EPV_FLAG_SAMPLE_ROOT,
+                "option bits");
   c->S.flags = flags;
   return EPV_OK;
 }
@@ -896,7 +895,7 @@ EPV_API int epv_get_options(epv_ctx *c, uint32_t *flags) {
 
 EPV_API int epv_phase_mode(epv_ctx *c, uint32_t *mode) {
   if (!c || !mode || !c->have_paths) return EPV_ERR_ARG;
-  const bool refq = c->S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO;
+  const bool refq = c->S.flags & (EPV_FLAG_REFERENCE_PROPOSAL_RATIO | EPV_FLAG_SAMPLE_ROOT);
   static const bool p2_global = std::getenv("EPV_PROPOSE_V2_GLOBAL") != nullptr;
   const bool p2 = c->use_p2 && !refq && (!c->p2_gpool || p2_global);
   *mode = !p2 ? EPV_PHASE_V1 : c->fused ? EPV_PHASE_FUSED : seg_jumps_on(c) ? EPV_PHASE_V2_SEGMENTS : EPV_PHASE_V2;

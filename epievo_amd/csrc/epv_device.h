@@ -97,6 +97,7 @@ struct EpvIndepConst {
 // run-time options (epv_set_options; the same values as the public header)
 #define EPV_FLAG_REFERENCE_PROPOSAL_RATIO 1u  /* evaluate q(old)/q(new) with the reference's sums */
 #define EPV_FLAG_FORWARD_REJECTION 2u         /* state-changing segments by forward rejection too */
+#define EPV_FLAG_SAMPLE_ROOT 4u               /* SingleSiteSampler::SAMPLE_ROOT: propose the root state too (reference arithmetic kernels) */
 
 // counters[] slots
 enum { EPV_CNT_ACCEPT = 0, EPV_CNT_OVERFLOW = 1, EPV_CNT_COOP = 2, EPV_CNT_TASKS = 3, EPV_CNT_TASKS2 = 4,

@@ -571,7 +571,29 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
     unsigned long long multi = 0ull;   // ... of those, the branches with an even bucket bit (K = 2 or K >= 4)
     unsigned long long deep = 0ull;    // ... and those with K >= 3 (second region)
     {
-      const uint32_t root_state = run ? (uint32_t)(S.meta[meta_idx(S, selM, 0u, site)] >> EPV_INIT_SHIFT) : 0u;
+      uint32_t root_state = run ? (uint32_t)(S.meta[meta_idx(S, selM, 0u, site)] >> EPV_INIT_SHIFT) : 0u;
+      if (REFQ && run && (S.flags & EPV_FLAG_SAMPLE_ROOT)) {
+        // SAMPLE_ROOT (SingleSiteSampler.cpp:167-176, :246-249, :325-329): the root state from its
+        // posterior given the neighbours' root states and the data below (q of node 0 = the product
+        // of the root's children's p.front); both log-probabilities carry the term
+        double q0 = 1.0, q1 = 1.0;
+        for (uint32_t ch = 1u; ch < S.subtree[0]; ch += S.subtree[ch]) {
+          const double *a = my + (size_t)(regA[ch * 64u + lane] & 0x7fffffffu) * RS;
+          q0 *= a[0];
+          q1 *= a[1];
+        }
+        const uint32_t rl = (uint32_t)(S.meta[meta_idx(S, selL, 0u, site - 1)] >> EPV_INIT_SHIFT);
+        const uint32_t rr = (uint32_t)(S.meta[meta_idx(S, selR, 0u, site + 1)] >> EPV_INIT_SHIFT);
+        const double *T = s_const + 16;
+        const double p0 = (T[2u * rl + 0u] * T[0u + rr]) * q0;
+        const double p1 = (T[2u * rl + 1u] * T[2u + rr]) * q1;
+        const double root_p0 = p0 / (p0 + p1);
+        const double u_root = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, 0u, 0u, 0u, 0u).d1;
+        const uint32_t cur_root = root_state;
+        root_state = (u_root > root_p0) ? 1u : 0u;
+        log_prob = root_state ? epv_log(1.0 - root_p0) : epv_log(root_p0);
+        orig_proposal = cur_root ? epv_log(1.0 - root_p0) : epv_log(root_p0);
+      }
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t b = node - 1u;
         if (run) {
@@ -949,7 +971,7 @@ __device__ __forceinline__ uint32_t epv_accept_site(const EpvDev &S, const doubl
   double llh_l = S.tri[site - 1];
   double llh_m = S.tri[site];
   double llh_r = S.tri[site + 1];
-  double llr = (S.flags & EPV_FLAG_REFERENCE_PROPOSAL_RATIO) ? S.prop_llr[tid] : 0.0;
+  double llr = (S.flags & (EPV_FLAG_REFERENCE_PROPOSAL_RATIO | EPV_FLAG_SAMPLE_ROOT)) ? S.prop_llr[tid] : 0.0;
   const double llh_l_orig = llh_l, llh_r_orig = llh_r;
   if (!ovf) {
     // the three triples centred at site-1, site, site+1 with the proposal standing in

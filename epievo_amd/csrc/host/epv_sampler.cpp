@@ -169,6 +169,7 @@ std::vector<epv_ctx *> SingleSiteSampler::contexts() const {
   return v;
 }
 void SingleSiteSampler::set_options(uint32_t flags) {
+  SAMPLE_ROOT = (flags & (uint32_t)EPV_OPT_SAMPLE_ROOT) != 0;
   for (epv_ctx *c : contexts()) check_on(c, epv_set_options(c, flags), "epv_set_options");
 }
 void SingleSiteSampler::set_timing(int every) {
@@ -320,13 +321,15 @@ void SingleSiteSampler::refresh_parts() {
 }
 
 // SAMPLE_ROOT (a public field of the reference class, hard-wired false at SingleSiteSampler.cpp:441 and
-// set by none of its programs) would resample the root state (:167-176, :246-249).  The kernels
-// keep the root state -- their exact proposal ratio holds only then -- so a caller that sets the
-// field is refused instead of silently getting the other chain.
-static void refuse_sample_root(bool sample_root) {
-  if (sample_root)
-    throw std::runtime_error("SingleSiteSampler::SAMPLE_ROOT = true is not supported by the MI355X sampler "
-                             "(root states are kept, as in every program of the reference)");
+// set by none of its programs): the proposal also draws the root state (:167-176, :246-249).  The
+// field is forwarded to every context as EPV_OPT_SAMPLE_ROOT before each call that runs updates.
+void SingleSiteSampler::apply_sample_root() {
+  for (epv_ctx *c : contexts()) {
+    uint32_t flags = 0;
+    check_on(c, epv_get_options(c, &flags), "epv_get_options");
+    const uint32_t want = SAMPLE_ROOT ? (flags | (uint32_t)EPV_OPT_SAMPLE_ROOT) : (flags & ~(uint32_t)EPV_OPT_SAMPLE_ROOT);
+    if (want != flags) check_on(c, epv_set_options(c, want), "epv_set_options");
+  }
 }
 
 // a halo that lasts one whole run_mcmc (two columns per colour phase), in whole blocks
@@ -353,14 +356,12 @@ std::vector<uint64_t> SingleSiteSampler::shard_cuts(uint64_t n, size_t world, si
 }
 
 void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &paths) {
-  refuse_sample_root(SAMPLE_ROOT);
   if (rank_mode_) throw std::runtime_error("one slot per process: reset(model, tree, owned columns, n_global)");
   build(th, paths, paths.n_sites, false);
   reset(m);
 }
 
 void SingleSiteSampler::reset(const Model &m, const Tree &th, const FlatPaths &owned, uint64_t n_global) {
-  refuse_sample_root(SAMPLE_ROOT);
   if (!rank_mode_) throw std::runtime_error("reset(..., n_global) belongs to the one-slot-per-process constructor");
   build(th, owned, n_global, true);
   reset(m);
@@ -494,7 +495,7 @@ void SingleSiteSampler::init_paths_indep(const Model &m, const Tree &th, const s
 }
 
 void SingleSiteSampler::reset(const Model &m) {
-  refuse_sample_root(SAMPLE_ROOT);
+  apply_sample_root();
   if (!sharded()) {
     check(epv_set_model(ctx_, m.rates.data(), m.T.data()), "epv_set_model");
     check(epv_reset(ctx_), "epv_reset");
@@ -536,7 +537,7 @@ void SingleSiteSampler::ensure_stat_buffers() {
 void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
                                  std::vector<std::vector<double>> &J,
                                  std::vector<std::vector<double>> &D, double &acceptance_rate) {
-  refuse_sample_root(SAMPLE_ROOT);
+  apply_sample_root();
   const size_t B = (size_t)n_nodes_ - 1;
   std::vector<double> Jf(B * 8), Df(B * 8);
   uint64_t n_acc = 0;
@@ -616,7 +617,7 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
 }
 
 size_t SingleSiteSampler::sweeps(size_t n, uint64_t seed, uint32_t sweep_base) {
-  refuse_sample_root(SAMPLE_ROOT);
+  apply_sample_root();
   uint64_t n_acc = 0;
   if (!sharded()) {
     check_mcmc(epv_sweep(ctx_, n, seed, sweep_base, &n_acc), "epv_sweep");

@@ -119,8 +119,8 @@ public:
   void indep_update_paths(const double rates[2], uint64_t seed, uint32_t sweep);
 
   // MCMC parameter constants (public fields of the reference class)
-  bool SAMPLE_ROOT;  // hard-wired false in the reference (SingleSiteSampler.cpp:441); true is REFUSED
-                     // (std::runtime_error from reset / run_mcmc / sweeps): the kernels keep the root state
+  bool SAMPLE_ROOT;  // hard-wired false in the reference (SingleSiteSampler.cpp:441); true = EPV_OPT_SAMPLE_ROOT on
+                     // every context (root states are proposed too; reference-arithmetic kernels)
   size_t burn_in;
   size_t batch;
 
@@ -160,6 +160,7 @@ private:
   bool sharded() const { return !parts_.empty(); }
   void drop_parts();          // back to the single context ctx_
   void refresh_parts();       // equal capacities, halo columns of every inner edge, fresh halo marks
+  void apply_sample_root();
   void build(const Tree &th, const FlatPaths &paths, uint64_t n_global, bool rank_mode);
   std::vector<epv_ctx *> contexts() const;
   void equalize_capacity();

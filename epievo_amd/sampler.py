@@ -192,10 +192,10 @@ class DeviceSampler:
                 return
         self._ck(rc)
 
-    def set_options(self, reference_proposal_ratio=False, forward_rejection=False):
+    def set_options(self, reference_proposal_ratio=False, forward_rejection=False, sample_root=False):
         """see EPV_OPT_* in include/epievo_mi355x.h"""
         self._ck(self.L.epv_set_options(self.h, (1 if reference_proposal_ratio else 0) |
-                                        (2 if forward_rejection else 0)))
+                                        (2 if forward_rejection else 0) | (4 if sample_root else 0)))
 
     PHASE_KERNELS = {
         0: "epv_mh_propose_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel",
@@ -455,20 +455,21 @@ class SingleSiteSampler:
     def __init__(self, n_burn_in, n_batch, device=0, capacity=0):
         self.burn_in, self.batch = int(n_burn_in), int(n_batch)
         # hard-wired false in the reference (SingleSiteSampler.cpp:441) and set by none of its programs;
-        # True is REFUSED by reset / run_mcmc / sweeps: the kernels keep the root state
+        # True = EPV_OPT_SAMPLE_ROOT: root states are proposed too (reference-arithmetic kernels)
         self.SAMPLE_ROOT = False
         self.capacity = capacity
         self.dev = DeviceSampler(device)
         self.dev.auto_grow = True     # paths grow on demand, as the reference's vectors do
         self._uploaded = False
 
-    def _refuse_sample_root(self):
-        if self.SAMPLE_ROOT:
-            raise EpvError(EPV_ERR_ARG, "SingleSiteSampler.SAMPLE_ROOT = True is not supported by the MI355X "
-                                        "sampler (root states are kept, as in every program of the reference)")
+    def _apply_sample_root(self):
+        flags = C.c_uint32(0)
+        self.dev._ck(self.dev.L.epv_get_options(self.dev.h, C.byref(flags)))
+        want = (flags.value | 4) if self.SAMPLE_ROOT else (flags.value & ~4)
+        if want != flags.value:
+            self.dev._ck(self.dev.L.epv_set_options(self.dev.h, want))
 
     def reset(self, model, tree, paths=None):
-        self._refuse_sample_root()
         self.dev.set_tree(tree)
         self.dev.set_model(model)
         if paths is not None:
@@ -476,17 +477,18 @@ class SingleSiteSampler:
             self._uploaded = True
         if not self._uploaded:
             raise EpvError(EPV_ERR_STATE, "reset() needs paths the first time")
+        self._apply_sample_root()
         self.dev.reset()
 
     def run_mcmc(self, seed, em_iter=0):
-        self._refuse_sample_root()
+        self._apply_sample_root()
         base = em_iter * (self.burn_in + self.batch)
         J, D, nacc = self.dev.run_mcmc(self.burn_in, self.batch, seed, base)
         acc_rate = nacc / float(self.batch * (self.dev.n_sites - 2))
         return J, D, acc_rate
 
     def sweeps(self, n, seed, sweep_base=0):
-        self._refuse_sample_root()
+        self._apply_sample_root()
         return self.dev.sweep(n, seed, sweep_base)
 
     def scale_jump_times(self, new_branches):

@@ -64,12 +64,15 @@ typedef struct {
  *     reference's hot path calls) instead of the reference library's
  *     end_cond_sampling_Nielsen (:576-617), the default here because its acceptance probability
  *     does not vanish on short branches.  Same conditional law; for parity tests.
- * EPV_OPT_SAMPLE_ROOT  the reference class's public field SAMPLE_ROOT (SingleSiteSampler.hpp:78;
- *     root_post_prob0 / downward_sampling, SingleSiteSampler.cpp:167-176, :246-249).  It is
- *     hard-wired false (:441) and none of the reference's programs sets it; the kernels keep the
- *     root state and their exact proposal ratio holds only then.  The bit is RESERVED so that a
- *     binding can forward the field: epv_set_options refuses it with EPV_ERR_ARG (as the C++ and
- *     Python mirrors refuse SAMPLE_ROOT = true) instead of silently running the other chain. */
+ * EPV_OPT_SAMPLE_ROOT  the reference class's public field SAMPLE_ROOT (SingleSiteSampler.hpp:78): the
+ *     proposal also draws the site's root state from its posterior given the neighbours' root
+ *     states and the data below (root_post_prob0 / downward_sampling, SingleSiteSampler.cpp:167-176,
+ *     :246-249) and both proposal log-probabilities carry the term (:325-329).  The reference
+ *     hard-wires it to false (:441) and none of its programs sets it.  With it the proposal ratio
+ *     is no longer identically 1, so the kernels evaluate it as under
+ *     EPV_OPT_REFERENCE_PROPOSAL_RATIO (the first-generation proposal kernel; about half the
+ *     default throughput).  Pinned: oracle rung A with the field set == the linked reference bit
+ *     for bit; the GPU == rung B bit for bit (tests/test_sample_root.py). */
 enum { EPV_OPT_REFERENCE_PROPOSAL_RATIO = 1, EPV_OPT_FORWARD_REJECTION = 2, EPV_OPT_SAMPLE_ROOT = 4 };
 
 /* Create a context on HIP device `device_id`.  Returns NULL when the device cannot be

@@ -116,6 +116,7 @@ typedef struct orc_state {
   /* counters */
   uint64_t n_overflow, n_trials, n_draws, n_segments;
   int proposal_mode;       /* ORC_PROPOSAL_* */
+  int sample_root;         /* SingleSiteSampler::SAMPLE_ROOT (hard-wired false in the reference, :441) */
   double max_qdiff;        /* max |proposal_prob(old) - proposal_prob(new)| seen (reference arithmetic) */
 } orc_state;
 
@@ -252,6 +253,14 @@ static inline double rng_segment_uniform(orc_rng *g, uint32_t b, uint32_t k) {
   orc_keyed_block(g->st->seed, g->site, g->sweep, b, k, 0, 0, d);
   return d[0];
 }
+/* the root state's uniform (SingleSiteSampler.cpp:247, SAMPLE_ROOT only): the FIRST draw of a site
+ * update in the reference's stream; the unused half of the accept uniform's block in the keyed one */
+static inline double rng_root_uniform(orc_rng *g) {
+  if (g->st->rng_mode == ORC_RNG_MT) return orc_mt_canonical(&g->st->mt);
+  double d[2];
+  orc_keyed_block(g->st->seed, g->site, g->sweep, 0, 0, 0, 0, d);
+  return d[1];
+}
 static inline double rng_accept_uniform(orc_rng *g) {
   if (g->st->rng_mode == ORC_RNG_MT) return orc_mt_canonical(&g->st->mt);
   double d[2];
@@ -347,12 +356,26 @@ static int forward_rejection(orc_state *st, orc_scratch *sc, orc_rng *g,
   }
 }
 
+/* root_post_prob0, SingleSiteSampler.cpp:167-176: posterior probability of state 0 at the root given
+ * the neighbours' root states and the data below (q of node 0) */
+static double root_post_prob0(const orc_state *st, size_t site, const orc_scratch *sc) {
+  const int l = PATH(st, 1, site - 1)->init, r = PATH(st, 1, site + 1)->init;
+  const double p0 = (st->T[2 * l + 0] * st->T[2 * 0 + r]) * sc->q0[0];
+  const double p1 = (st->T[2 * l + 1] * st->T[2 * 1 + r]) * sc->q1[0];
+  return p0 / (p0 + p1);
+}
+
 /* SingleSiteSampler.cpp:180-255.  Returns 1 if the proposal overflowed. */
 static int downward_sampling(orc_state *st, size_t site, orc_scratch *sc, orc_rng *g,
                              double *log_prob_out) {
   double log_prob = 0.0;
   int overflow = 0;
-  const int root_state = PATH(st, 1, site)->init; /* SAMPLE_ROOT == false (:246) */
+  int root_state = PATH(st, 1, site)->init; /* SAMPLE_ROOT == false (:246) */
+  if (st->sample_root) {                    /* :246-249 */
+    const double root_p0 = root_post_prob0(st, site, sc);
+    root_state = rng_root_uniform(g) > root_p0;
+    log_prob = root_state ? st->flog(1.0 - root_p0) : st->flog(root_p0);
+  }
   sc->prop[0].init = (uint8_t)root_state;
   sc->prop[0].n = 0;
   for (int node = 1; node < st->n_nodes; ++node) {
@@ -395,6 +418,10 @@ static int downward_sampling(orc_state *st, size_t site, orc_scratch *sc, orc_rn
 /* SingleSiteSampler.cpp:272-339 */
 static double proposal_prob(const orc_state *st, size_t site, const orc_scratch *sc) {
   double log_prob = 0.0;
+  if (st->sample_root) {   /* :325-329 */
+    const double root_p0 = root_post_prob0(st, site, sc);
+    log_prob += PATH(st, 1, site)->init ? st->flog(1.0 - root_p0) : st->flog(root_p0);
+  }
   for (int node = 1; node < st->n_nodes; ++node) {
     const orc_segs *s = &sc->segs[node];
     const orc_path *path = PATH(st, node, site);
@@ -625,6 +652,12 @@ ORC_API void orc_set_modes(orc_state *st, int rng_mode, int math_mode, int sched
 }
 ORC_API void orc_set_sampler(orc_state *st, int sampler_mode) { st->sampler_mode = sampler_mode; }
 ORC_API void orc_set_proposal_mode(orc_state *st, int mode) { st->proposal_mode = mode; }
+/* SAMPLE_ROOT: the proposal then includes the root state, whose posterior does not cancel against
+ * the (un-logged) root prior of the likelihood: the ratio must be evaluated, never elided */
+ORC_API void orc_set_sample_root(orc_state *st, int on) {
+  st->sample_root = on;
+  if (on) st->proposal_mode = ORC_PROPOSAL_REFERENCE;
+}
 ORC_API double orc_get_max_qdiff(const orc_state *st) { return st->max_qdiff; }
 ORC_API void orc_seed_mt(orc_state *st, uint64_t seed) { orc_mt_seed(&st->mt, (uint32_t)seed); }
 ORC_API void orc_seed_philox(orc_state *st, uint64_t seed) { st->seed = seed; }

@@ -97,12 +97,16 @@ void ref_set_model(void *h, const double *rates, const double *T) {
 void ref_seed(void *h, uint64_t seed) { static_cast<RefState *>(h)->gen.seed(seed); }
 
 /* SingleSiteSampler(burn_in, batch) + reset(), as est_params_histories.cpp:236,241 */
+static bool g_sample_root = false;
 void ref_reset(void *h, uint64_t burn_in, uint64_t batch) {
   RefState *st = static_cast<RefState *>(h);
   delete st->mcmc;
   st->mcmc = new SingleSiteSampler(burn_in, batch);
+  st->mcmc->SAMPLE_ROOT = g_sample_root;
   st->mcmc->reset(st->model, st->paths);
 }
+/* the public field SingleSiteSampler::SAMPLE_ROOT (SingleSiteSampler.hpp:78) for the samplers made afterwards */
+void ref_set_sample_root(int on) { g_sample_root = on != 0; }
 
 /* what reset() caches privately: path_log_likelihood of every interior triple */
 void ref_tri_llh(void *h, double *out) {

@@ -56,6 +56,7 @@ def orc_lib():
         L.orc_suffstats_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64)]
         L.orc_stat_scales.argtypes = [C.c_void_p, dp]
         L.orc_set_proposal_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_sample_root.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_sampler.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_max_qdiff.argtypes = [C.c_void_p]
         L.orc_get_max_qdiff.restype = C.c_double
@@ -140,6 +141,8 @@ def ref_lib():
                                         C.c_uint32, dp, C.c_double, dp, dp]
         L.ref_kat_expectations.argtypes = [C.c_double, C.c_double, C.c_double, dp]
         L.ref_kat_mt_canonical.argtypes = [C.c_uint64, C.c_uint64, dp]
+        if hasattr(L, 'ref_set_sample_root'):
+            L.ref_set_sample_root.argtypes = [C.c_int]
         if hasattr(L, 'ref_indep_expectation'):
             L.ref_indep_expectation.argtypes = [C.c_void_p, dp, dp, dp]
             L.ref_indep_suffstats.argtypes = [C.c_void_p, dp, dp]
@@ -236,6 +239,10 @@ class Oracle(_Engine):
     def set_proposal_mode(self, reference):
         """True: q(old)/q(new) by the reference's sums; False: the exact (telescoped) 0"""
         self.L.orc_set_proposal_mode(self.h, 0 if reference else 1)
+
+    def set_sample_root(self, on):
+        """SingleSiteSampler::SAMPLE_ROOT (forces the reference's proposal-ratio arithmetic)"""
+        self.L.orc_set_sample_root(self.h, 1 if on else 0)
 
     def set_sampler(self, forward):
         """True: forward rejection for every segment; False: Nielsen for state changes"""

@@ -117,26 +117,3 @@ def test_paths_at_full_capacity_survive_roundtrip_and_sweeps():
         o.sweep(w)
         assert orc.paths_equal(d.paths(), o.paths())
     assert d.counters()["overflow"] == o.counters()["overflow"]
-
-
-def test_sample_root_is_refused_by_every_mirror():
-    """SAMPLE_ROOT (public field of the reference class, SingleSiteSampler.hpp:78) is hard-wired
-    false there; the kernels keep the root state, so `true` is refused, never ignored"""
-    import ctypes as C
-    from epievo_amd.sampler import SingleSiteSampler
-    model, tree, fp = simulate("tree", 300, seed=2)
-    m = SingleSiteSampler(1, 1)
-    m.reset(model, tree, fp)
-    m.SAMPLE_ROOT = True
-    for call in (lambda: m.reset(model, tree), lambda: m.run_mcmc(1), lambda: m.sweeps(1, 1)):
-        with pytest.raises(EpvError) as e:
-            call()
-        assert e.value.code == EPV_ERR_ARG and "SAMPLE_ROOT" in str(e.value)
-    m.SAMPLE_ROOT = False
-    m.run_mcmc(1)
-    # the C ABI reserves the option bit and refuses it
-    d = m.dev
-    rc = d.L.epv_set_options(d.h, C.c_uint32(4))
-    assert rc == EPV_ERR_ARG and b"SAMPLE_ROOT" in d.L.epv_last_error(d.h)
-    flags = C.c_uint32(99)
-    assert d.L.epv_get_options(d.h, C.byref(flags)) == 0 and flags.value == 0
