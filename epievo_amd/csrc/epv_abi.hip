@@ -1338,13 +1338,25 @@ EPV_API int epv_run_mcmc_blocks(epv_ctx *c, uint64_t burn_in, uint64_t batch, ui
   }
   uint64_t base = 0;
   if ((rc = current_accepts(c, &base))) return rc;
+  // the statistics of a context that shares its GPU with others run as one-wave blocks (they fit
+  // into the LDS the colour phases leave free); the waves of a 256-site block add into its row, so
+  // this context's rows start from zero.  EPV_STAT_BLOCKS=1: the 256-lane kernel (A/B runs)
+  static const bool stat_blocks = std::getenv("EPV_STAT_BLOCKS") != nullptr;
+  unsigned long long *rows0 = (unsigned long long *)d_blocks + (uint64_t)(block_offset + (int64_t)blk_lo) * V;
+  const uint64_t n_own = blk_hi - blk_lo + 1u;
+  if (!stat_blocks)
+    HIP_TRY(c, hipMemset2DAsync(rows0, nb_total * V * sizeof(unsigned long long), 0, n_own * V * sizeof(unsigned long long),
+                                batch, c->stream));
   for (uint64_t w = 0; w < batch; ++w, ++sweep) {
     for (int colour = 0; colour < 3; ++colour)
       if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
     ++c->n_sweeps;
-    hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)(blk_hi - blk_lo + 1u), (c->S.B + EPV_STAT_BCH - 1u) / EPV_STAT_BCH),
-                       dim3(256), 0, c->stream, c->S, own_lo, own_hi, blk_lo, c->d_statscale,
-                       (unsigned long long *)d_blocks + (w * nb_total + (uint64_t)(block_offset + (int64_t)blk_lo)) * V);
+    if (stat_blocks)
+      hipLaunchKernelGGL(epv_suffstat_kernel, dim3((unsigned)n_own, (c->S.B + EPV_STAT_BCH - 1u) / EPV_STAT_BCH),
+                         dim3(256), 0, c->stream, c->S, own_lo, own_hi, blk_lo, c->d_statscale, rows0 + w * nb_total * V);
+    else
+      hipLaunchKernelGGL(epv_suffstat_wave_kernel, dim3((unsigned)(n_own * 4u), (c->S.B + EPV_STATW_BCH - 1u) / EPV_STATW_BCH),
+                         dim3(64), 0, c->stream, c->S, own_lo, own_hi, blk_lo, c->d_statscale, rows0 + w * nb_total * V);
   }
   HIP_TRY(c, hipGetLastError());
   return finish_mcmc(c, n_accepted, base);  // synchronises the stream

@@ -222,9 +222,9 @@ __device__ __forceinline__ bool epv_seg_search_grouped(const EpvDev &S, const do
 __device__ __forceinline__ void epv_seg_assemble_one(const EpvDev &S, const double *s_rates, const EpvSegTask *segs,
                                                      const EpvSegOut *outs, unsigned long long bt, uint64_t first,
                                                      uint64_t s0, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
-                                                     bool nielsen, uint32_t *node_table = nullptr, uint64_t site_lane0 = 0) {
-  // node_table (fused phase): the wave's LDS table [node][lane]; the branch's jump count goes into
-  // bits 14..24 of its owner's entry, where the acceptance stage picks it up
+                                                     bool nielsen, epv_meta_t *prop_meta = nullptr, uint64_t site_lane0 = 0) {
+  // prop_meta (fused phase): the wave's LDS column [branch][lane] of proposal meta words; the
+  // assembled branch's word goes to its owner's entry, where the acceptance stage picks it up
   const uint64_t n = S.n;
   const uint32_t B = S.B, C = S.C;
   const uint64_t site = bt & 0xffffffffffull;
@@ -261,10 +261,7 @@ __device__ __forceinline__ void epv_seg_assemble_one(const EpvDev &S, const doub
     S.prop_flag[(site - s0) / 3u] = 1u;
   }
   *meta = (epv_meta_t)((start_state << EPV_INIT_SHIFT) | cnt);
-  if (node_table) {
-    uint32_t *e = node_table + (b + 1u) * 64u + (uint32_t)((site - site_lane0) / 3u);
-    *e = (*e & ~(0x7ffu << 14)) | (cnt << 14);
-  }
+  if (prop_meta) prop_meta[b * 64u + (uint32_t)((site - site_lane0) / 3u)] = (epv_meta_t)((start_state << EPV_INIT_SHIFT) | cnt);
 }
 
 // one lane per dirty branch: the results of its dirty segments, in order, into the proposal

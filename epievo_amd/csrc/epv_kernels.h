@@ -1541,6 +1541,117 @@ __global__ __launch_bounds__(256) void epv_suffstat_kernel(EpvDev S, uint64_t fi
   }
 }
 
+// The same statistics with ONE WAVE per block and ~2 KB of LDS, for launches that run next to other
+// contexts' colour phases: those fill the CUs' LDS to within 11 KB (nine 16.5 KB blocks of 160 KB), so
+// a 256-lane block with 11.5 KB waits for a colour-phase block to leave and then keeps the next one
+// out, while a one-wave block slips into the gap.  64 sites and up to EPV_STATW_BCH branches per
+// block; neighbours' meta words through LDS, no block barrier; the four waves of a 256-site block add
+// their sums into the block's row of `partial` with 64-bit atomics (the row must be zero: integer sums
+// commute, so the result is the one of epv_suffstat_kernel).
+#define EPV_STATW_BCH 8u
+__global__ __launch_bounds__(64) void epv_suffstat_wave_kernel(EpvDev S, uint64_t first, uint64_t last, uint64_t block0,
+                                                               const double *statscale, unsigned long long *partial) {
+  __shared__ unsigned long long s_acc[EPV_STATW_BCH * 16u];
+  __shared__ uint32_t s_cnt[EPV_STATW_BCH * 8u];
+  __shared__ epv_meta_t s_meta[66];
+  __shared__ uint8_t s_sel[66];
+  __shared__ uint32_t s_ring[128], s_ring_lm[128];
+  __shared__ epv_meta_t s_ring_r[128];
+  const uint32_t t = threadIdx.x;
+  const int lane = (int)t;
+  const uint32_t B = S.B;
+  const uint32_t b_lo = blockIdx.y * EPV_STATW_BCH, b_hi = (b_lo + EPV_STATW_BCH < B) ? b_lo + EPV_STATW_BCH : B;
+  const uint64_t n = S.n, Bn = (uint64_t)B * n, Cn = (uint64_t)S.C * n;
+  const uint64_t site0 = block0 * 256u + (uint64_t)blockIdx.x * 64u, site = site0 + t;
+  const bool on = site >= first && site <= last && site >= 1 && site + 1 < n;
+  const uint32_t my_sel = site < n ? S.sel[site] : 0u;
+  const bool edge = (t == 0 && site0 >= 1) || (t == 1 && site0 + 64u < n);
+  const uint64_t esite = t == 0 ? site0 - 1 : site0 + 64u;
+  const uint32_t e_sel = edge ? S.sel[esite] : 0u;
+  for (uint32_t i = t; i < EPV_STATW_BCH * 16u; i += 64u) s_acc[i] = 0ull;
+  s_cnt[t] = 0u;     // EPV_STATW_BCH * 8 = 64 entries
+  s_sel[t + 1u] = (uint8_t)my_sel;
+  if (t < 2u) s_sel[t == 0 ? 0 : 65] = (uint8_t)e_sel;
+  const uint64_t mbase = (my_sel ? Bn : 0ull) + site;
+  const uint64_t ebase = (e_sel ? Bn : 0ull) + esite;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  auto merge_item = [&](uint32_t slot) __attribute__((always_inline)) {
+    const uint32_t item = s_ring[slot], lm = s_ring_lm[slot], mr = s_ring_r[slot];
+    const uint32_t ti = item & 63u, bl = item >> 8, b = b_lo + bl;
+    const uint64_t si = site0 + ti;
+    const uint32_t ml = lm & 0xffffu, mm = lm >> 16;
+    PathRef L, M, R;
+    L.j = S.jumps + (s_sel[ti] ? Bn * S.C : 0ull) + (uint64_t)b * Cn + (si - 1); L.nj = ml & EPV_NJ_MASK; L.init = ml >> EPV_INIT_SHIFT;
+    M.j = S.jumps + (s_sel[ti + 1u] ? Bn * S.C : 0ull) + (uint64_t)b * Cn + si; M.nj = mm & EPV_NJ_MASK; M.init = mm >> EPV_INIT_SHIFT;
+    R.j = S.jumps + (s_sel[ti + 2u] ? Bn * S.C : 0ull) + (uint64_t)b * Cn + (si + 1); R.nj = mr & EPV_NJ_MASK; R.init = mr >> EPV_INIT_SHIFT;
+    AccExact A;
+    A.acc = s_acc + bl * 16u;
+    A.scale = statscale[b + 1u];
+    merge3(L, M, R, n, S.blen[b + 1u], A);
+  };
+
+  uint32_t head = 0u, tail = 0u;     // wave-uniform
+  constexpr uint32_t GB = 4u;
+  for (uint32_t b0 = b_lo; b0 < b_hi; b0 += GB) {
+    epv_meta_t mq[GB], eq[GB];
+#pragma unroll
+    for (uint32_t q = 0; q < GB; ++q) {
+      const bool have = b0 + q < b_hi;
+      mq[q] = (have && site < n) ? S.meta[mbase + (uint64_t)(b0 + q) * n] : (epv_meta_t)0;
+      eq[q] = (have && edge) ? S.meta[ebase + (uint64_t)(b0 + q) * n] : (epv_meta_t)0;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < GB; ++q) {
+      const uint32_t b = b0 + q;
+      if (b >= b_hi) break;
+      const uint32_t m = mq[q];
+      s_meta[t + 1u] = (epv_meta_t)m;
+      if (t < 2u) s_meta[t == 0 ? 0 : 65] = eq[q];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t ml = s_meta[t], mr = s_meta[t + 2u];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();     // everybody has read: the next branch may overwrite
+      const uint32_t or3 = (ml | m | mr) & EPV_NJ_MASK;
+      const bool fast = on && or3 == 0u, slow = on && or3 != 0u;
+      const unsigned long long mf = __ballot(fast), m2 = __ballot((ml >> EPV_INIT_SHIFT) != 0u),
+                               m1 = __ballot((m >> EPV_INIT_SHIFT) != 0u), m0 = __ballot((mr >> EPV_INIT_SHIFT) != 0u);
+      if (lane < 8) {
+        const unsigned long long x = mf & ((lane & 4) ? m2 : ~m2) & ((lane & 2) ? m1 : ~m1) & ((lane & 1) ? m0 : ~m0);
+        s_cnt[(b - b_lo) * 8u + (uint32_t)lane] += (uint32_t)__popcll(x);     // this lane's own counter
+      }
+      const unsigned long long ms = __ballot(slow);
+      if (slow) {
+        const uint32_t slot = (tail + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull))) & 127u;
+        s_ring[slot] = t | ((b - b_lo) << 8);
+        s_ring_lm[slot] = ml | (m << 16);
+        s_ring_r[slot] = (epv_meta_t)mr;
+      }
+      tail += (uint32_t)__popcll(ms);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (tail - head >= 64u) {
+        merge_item((head + t) & 127u);
+        head += 64u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  if (t < tail - head) merge_item((head + t) & 127u);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint64_t row = (site0 - block0 * 256u) / 256u;      // the 256-site block this wave belongs to
+  for (uint32_t i = t; i < (b_hi - b_lo) * 16u; i += 64u) {
+    const uint32_t bl = i >> 4, c = i & 15u, b = b_lo + bl;
+    unsigned long long v = s_acc[i];
+    if (c >= 8u) v += (unsigned long long)s_cnt[bl * 8u + (c - 8u)] * epv_stat_fix(S.blen[b + 1u] - 0.0, statscale[b + 1u]);
+    if (v) atomicAdd(&partial[(row * B + b) * 16u + c], v);
+  }
+}
+
 // Sums of rows of 64-bit integers: out(r, z, c) = the sum of the G consecutive input rows
 // r*G .. r*G+G-1 (rows >= m do not exist; G = 0: all m rows) of column c in slice z.  A block takes 16
 // columns and walks the rows 16 at a time (a wave reads four 128-byte pieces per load).  Integer sums

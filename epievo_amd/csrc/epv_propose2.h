@@ -480,9 +480,12 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         hrec0 = hcur;
         if (K >= 2u) hcur += K;
         if (!FUSED && (K & 63u) && !clean) states[(K - 1u) >> 6] = word;   // only a dirty branch is read back
-        // proposal end state for the children (bit 31), start state (bit 30); bits 14..24 take the
-        // jump count when the fused phase has assembled the branch
-        regA[node * 64u + lane] = off | (prev << 31) | (start_state << 30);
+        regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children
+        // the proposal's meta word (start state, no jumps yet; the fused phase's assembly adds the
+        // count) takes the place of the current path's, which this lane has just read for the last
+        // time: the acceptance stage finds it there.  (NOT in the node table: a later round of this
+        // wave lists its heavy pairs over the finished lanes' rows.)
+        if (FUSED) s_meta[(2u * B + b) * 64u + lane] = (epv_meta_t)(start_state << EPV_INIT_SHIFT);
         // same as the current path?  (no jumps on either, same start state)
         ident = ident && clean && mM == (start_state << EPV_INIT_SHIFT);
         dirty_b = !clean;
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       P2_MARK(7);
       for (uint32_t i = (uint32_t)lane; i < (EPV_DBG_SKIP < 2 ? f_nbt : 0u); i += 64u)
         epv_seg_assemble_one(S, s_rates, segs, outs, F.bt[f_wave * F.bt_cap + i], F.bfirst[f_wave * F.bt_cap + i], s0,
-                             seed_lo, seed_hi, sweep, nielsen, regA, site - 3u * (uint64_t)lane);
+                             seed_lo, seed_hi, sweep, nielsen, s_meta + 2u * B * 64u, site - 3u * (uint64_t)lane);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
       P2_MARK(8);
@@ -701,13 +704,11 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
           if (F.meta_cache) {
             // the meta words of the triple's columns without a global round trip: the neighbours'
             // current paths were staged at the head of the kernel (they belong to other colours and
-            // do not change in this phase), the proposal's are the start states of the node table
-            // and the counts the assembly left there
+            // do not change in this phase), the proposal's sit where the site's own column was
             const uint32_t B2 = S.B;
 #pragma unroll 4
             for (uint32_t b = 0; b < B2; ++b) {
-              const uint32_t ra = regA[(b + 1u) * 64u + o];
-              const epv_meta_t mP = (epv_meta_t)((((ra >> 30) & 1u) << EPV_INIT_SHIFT) | ((ra >> 14) & 0x7ffu));
+              const epv_meta_t mP = s_meta[(2u * B2 + b) * 64u + o];
               const epv_meta_t mL = s_meta[(0u * B2 + b) * 64u + o], mR = s_meta[(1u * B2 + b) * 64u + o];
               epv_meta_t m0, m1, m2;
               if (w == 0u) { m0 = o > 0u ? s_meta[(1u * B2 + b) * 64u + (o - 1u)] : s_edge[b]; m1 = mL; m2 = mP; }

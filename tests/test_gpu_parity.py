@@ -323,3 +323,36 @@ def test_phase_mode_follows_the_workload():
     model, tree, fp = simulate("bal16", 2000, seed=6)
     d3 = DeviceSampler(0); d3.set_tree(tree); d3.set_model(model); d3.upload_paths(fp, 16); d3.reset()
     assert d3.phase_mode() == 0             # record pool in global memory: first proposal kernel
+
+
+@pytest.mark.parametrize("scale,n", [(4.0, 30000), (3.0, 20000)])
+def test_fused_phase_with_many_heavy_branches_and_several_rounds(scale, n, monkeypatch):
+    """long branches on the tree.nwk topology (0.5 - 2 jumps per path): most (site, branch) pairs are
+    heavy, a wave's records exceed its LDS pool, so waves run the update in several ROUNDS over
+    prefixes of their lanes and later rounds list their heavy pairs over the node-table rows of lanes
+    that have finished -- the stages behind the rounds (segment search, assembly, acceptance) must not
+    depend on those rows.  Fused phase forced; bit-exact against rung B"""
+    from common import tree_nwk
+    from epievo_amd import host
+    from epievo_amd.sampler import DeviceSampler
+    monkeypatch.setenv("EPV_FUSED_PHASE", "1")
+    model = simulate("tree", 100, seed=1)[0]
+    t0 = tree_nwk()
+    tree = host.Tree(t0.subtree_sizes, t0.parent_ids, t0.branches * scale)
+    fp = host.simulate(model, tree, n, 77)
+    assert fp.counts().mean() > 0.15 * scale / 4.0
+    cap = int(max(16, min(31, 2 * fp.counts().max() + 8)))      # 2 C + 1 <= 64: the fused phase stays eligible
+    d = DeviceSampler(0); d.set_tree(tree); d.set_model(model); d.upload_paths(fp, cap); d.reset()
+    assert d.phase_mode() == 3
+    o = orc.Oracle(tree, model, fp, "B", cap=cap, seed=41); o.reset()
+    for w in range(3):
+        try:
+            na = d.sweep(1, 41, sweep_base=w)
+        except CapacityError:
+            na = None
+        nb = o.sweep(w)
+        assert na is None or na == nb
+        assert orc.paths_equal(d.paths(), o.paths())
+    assert np.array_equal(d.tri_llh(), o.tri_llh())
+    assert d.counters()["overflow"] == o.counters()["overflow"]
+    d.close()
