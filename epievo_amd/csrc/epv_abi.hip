@@ -39,6 +39,8 @@ struct epv_ctx {
   double *d_blen = nullptr;
   unsigned long long *d_counters = nullptr;
   unsigned long long *h_counters = nullptr;  // pinned staging for the sharded counters
+  unsigned long long *d_cnt_snap = nullptr;  // the counters as they stood when the batch sweeps began (stream-ordered copy:
+  unsigned long long *h_cnt_snap = nullptr;  // the host does not wait for the burn-in to read the accept base)
   double *d_partial[2] = {nullptr, nullptr};  // tree-reduction ping-pong
   uint64_t partial_cap[2] = {0, 0};   // doubles allocated in d_partial[0], [1]
   unsigned long long *d_sweep_tot = nullptr;  // [sweep][B*16] integer statistics of the batch sweeps
@@ -52,6 +54,7 @@ struct epv_ctx {
   uint64_t rows_cap = 0;
   uint8_t *d_stage = nullptr;   // packed-column staging for the halo exchange (grown on demand)
   uint64_t stage_cap = 0;
+  hipEvent_t ev_copy[2] = {nullptr, nullptr};   // epv_copy_columns_async: "slot s of my staging buffer is packed"
   EpvIndepConst *d_indep = nullptr;  // [N] constants of the site-independent model
   // launch shape of the MH kernel
   uint32_t mh_threads = 64, pool_entries = 0;
@@ -624,6 +627,8 @@ EPV_API epv_ctx *epv_create(int device_id) {
       hipMalloc(&c->d_model, sizeof(EpvModelConst)) != hipSuccess ||
       hipMalloc(&c->d_counters, sizeof(unsigned long long) * EPV_CNT_WORDS) != hipSuccess ||
       hipHostMalloc(&c->h_counters, sizeof(unsigned long long) * EPV_CNT_WORDS) != hipSuccess ||
+      hipMalloc(&c->d_cnt_snap, sizeof(unsigned long long) * EPV_CNT_WORDS) != hipSuccess ||
+      hipHostMalloc(&c->h_cnt_snap, sizeof(unsigned long long) * EPV_CNT_WORDS) != hipSuccess ||
       hipMemset(c->d_counters, 0, sizeof(unsigned long long) * EPV_CNT_WORDS) != hipSuccess) {
     delete c;
     return nullptr;
@@ -658,6 +663,9 @@ EPV_API void epv_destroy(epv_ctx *c) {
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
   dfree(c->d_counters); dfree(c->d_sweep_tot); dfree(c->d_statscale); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_segtab);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
+  if (c->h_cnt_snap) (void)hipHostFree(c->h_cnt_snap);
+  for (hipEvent_t &e : c->ev_copy) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  dfree(c->d_cnt_snap);
   for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1219,6 +1227,24 @@ static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base) {
   return EPV_OK;
 }
 
+// the accept counters of this moment of the stream, kept on the device; finish_mcmc_snapshot reads them
+// back together with the final ones -- no host synchronisation in the middle of a run
+static int snapshot_counters(epv_ctx *c) {
+  HIP_TRY(c, hipMemcpyAsync(c->d_cnt_snap, c->d_counters, sizeof(unsigned long long) * EPV_CNT_WORDS,
+                            hipMemcpyDeviceToDevice, c->stream));
+  return EPV_OK;
+}
+static int finish_mcmc_snapshot(epv_ctx *c, uint64_t *n_accepted) {
+  HIP_TRY(c, hipMemcpyAsync(c->h_cnt_snap, c->d_cnt_snap, sizeof(unsigned long long) * EPV_CNT_WORDS,
+                            hipMemcpyDeviceToHost, c->stream));
+  uint64_t total = 0;
+  int rc = finish_mcmc(c, &total, 0);      // synchronises the stream
+  uint64_t base = 0;
+  for (uint32_t sh = 0; sh < EPV_SHARDS; ++sh) base += c->h_cnt_snap[EPV_CNT_IDX(EPV_CNT_ACCEPT, sh)];
+  if (n_accepted) *n_accepted = total - base;
+  return rc;
+}
+
 static int current_accepts(epv_ctx *c, uint64_t *out) {
   unsigned long long cnt[EPV_CNT_N];
   int rc = read_counters(c, cnt);
@@ -1267,9 +1293,9 @@ EPV_API int epv_run_mcmc_sums(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint
       if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
     ++c->n_sweeps;
   }
-  uint64_t base = 0;
-  if ((rc = current_accepts(c, &base))) return rc;
   if ((rc = ensure_sweep_tot(c, batch))) return rc;
+  if ((rc = ensure_partials(c))) return rc;      // (allocations synchronise: before the snapshot)
+  if ((rc = snapshot_counters(c))) return rc;
   for (uint64_t w = 0; w < batch; ++w, ++sweep) {
     for (int colour = 0; colour < 3; ++colour)
       if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
@@ -1277,7 +1303,7 @@ EPV_API int epv_run_mcmc_sums(epv_ctx *c, uint64_t burn_in, uint64_t batch, uint
     if ((rc = launch_suffstats(c, w))) return rc;
   }
   HIP_TRY(c, hipGetLastError());
-  rc = finish_mcmc(c, n_accepted, base);  // synchronises the stream
+  rc = finish_mcmc_snapshot(c, n_accepted);  // synchronises the stream
   const int src = finish_stats(c, batch, average, J, D);
   return rc ? rc : src;
 }
@@ -1336,8 +1362,7 @@ EPV_API int epv_run_mcmc_blocks(epv_ctx *c, uint64_t burn_in, uint64_t batch, ui
       if ((rc = launch_phase(c, colour, seed, sweep))) return rc;
     ++c->n_sweeps;
   }
-  uint64_t base = 0;
-  if ((rc = current_accepts(c, &base))) return rc;
+  if ((rc = snapshot_counters(c))) return rc;
   // the statistics of a context that shares its GPU with others run as one-wave blocks (they fit
   // into the LDS the colour phases leave free); the waves of a 256-site block add into its row, so
   // this context's rows start from zero.  EPV_STAT_BLOCKS=1: the 256-lane kernel (A/B runs)
@@ -1359,7 +1384,7 @@ EPV_API int epv_run_mcmc_blocks(epv_ctx *c, uint64_t burn_in, uint64_t batch, ui
                          dim3(64), 0, c->stream, c->S, own_lo, own_hi, blk_lo, c->d_statscale, rows0 + w * nb_total * V);
   }
   HIP_TRY(c, hipGetLastError());
-  return finish_mcmc(c, n_accepted, base);  // synchronises the stream
+  return finish_mcmc_snapshot(c, n_accepted);  // synchronises the stream
 }
 
 EPV_API int epv_reduce_blocks(epv_ctx *c, const double *d_blocks, uint64_t nb_total, uint64_t batch,
@@ -1577,6 +1602,40 @@ EPV_API int epv_copy_columns(epv_ctx *src, uint64_t src_first, uint64_t count, e
                      dst_first, count, src->d_stage);
   HIP_TRY(dst, hipGetLastError());
   HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+  return EPV_OK;
+}
+
+// the same without a host synchronisation: the columns are packed on src's stream into half `slot`
+// (0 or 1) of its staging buffer and unpacked on dst's stream behind an event -- whatever the caller
+// launches on dst's stream afterwards (epv_reset) sees them; src must not be asked for the same slot
+// again before dst's stream has passed the unpack
+EPV_API int epv_copy_columns_async(epv_ctx *src, uint64_t src_first, uint64_t count, epv_ctx *dst,
+                                   uint64_t dst_first, int slot) {
+  int rc = check_ready(src, false);
+  if (rc) return rc;
+  if ((rc = check_ready(dst, false))) return rc;
+  if (slot < 0 || slot > 1) return fail(dst, EPV_ERR_ARG, "slot must be 0 or 1");
+  if (src->device != dst->device || src->S.B != dst->S.B || src->S.C != dst->S.C)
+    return fail(dst, EPV_ERR_ARG, "epv_copy_columns_async needs two contexts of one GPU with equal tree and capacity");
+  if (src_first + count > src->S.n || dst_first + count > dst->S.n) return fail(dst, EPV_ERR_ARG, "bad column range");
+  if (count == 0) return EPV_OK;
+  HIP_TRY(src, hipSetDevice(src->device));
+  const uint64_t bytes = count * epv_column_bytes(src);
+  if (2u * bytes > src->stage_cap) {
+    // (growing the buffer waits for both streams: a half of it may still be read)
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    if ((rc = ensure_stage(src, 2u * bytes))) return rc;
+  }
+  if (!src->ev_copy[slot]) HIP_TRY(src, hipEventCreateWithFlags(&src->ev_copy[slot], hipEventDisableTiming));
+  uint8_t *stage = src->d_stage + (slot ? src->stage_cap / 2u : 0u);
+  hipLaunchKernelGGL(epv_pack_columns_kernel, dim3((unsigned)count), dim3(64), 0, src->stream, src->S,
+                     src_first, count, stage);
+  HIP_TRY(src, hipGetLastError());
+  HIP_TRY(src, hipEventRecord(src->ev_copy[slot], src->stream));
+  HIP_TRY(dst, hipStreamWaitEvent(dst->stream, src->ev_copy[slot], 0));
+  hipLaunchKernelGGL(epv_unpack_columns_kernel, dim3((unsigned)count), dim3(64), 0, dst->stream, dst->S,
+                     dst_first, count, stage);
+  HIP_TRY(dst, hipGetLastError());
   return EPV_OK;
 }
 

@@ -279,8 +279,10 @@ void SingleSiteSampler::refresh_parts() {
   for (size_t p = 0; p + 1 < P; ++p) {
     Part &L = parts_[p], &R = parts_[p + 1];
     if (L.slot != R.slot) continue;
-    check_on(R.ctx, epv_copy_columns(L.ctx, L.b - H - L.lo, H, R.ctx, 0), "epv_copy_columns");
-    check_on(L.ctx, epv_copy_columns(R.ctx, H, H, L.ctx, L.b - L.lo), "epv_copy_columns");
+    // (no host wait: the unpack sits on the receiving context's stream, in front of its reset;
+    // a part's right-going edge uses half 0 of its staging buffer, its left-going edge half 1)
+    check_on(R.ctx, epv_copy_columns_async(L.ctx, L.b - H - L.lo, H, R.ctx, 0, 0), "epv_copy_columns_async");
+    check_on(L.ctx, epv_copy_columns_async(R.ctx, H, H, L.ctx, L.b - L.lo, 1), "epv_copy_columns_async");
   }
   // between two GPU slots: the first part of a slot sends its left edge to the slot before it, the
   // last part its right edge to the slot after it -- one exchange call per slot that lives here

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "epv_run_mcmc_blocks", "epv_reduce_blocks", "epv_get_counters", "epv_kernel_time_ms",
     "epv_set_timing", "epv_pack_columns_dev", "epv_unpack_columns_dev", "epv_device_of",
     "epv_blocks_to_rows", "epv_reduce_rows", "epv_reduce_gathered_rows", "epv_dev_write", "epv_dev_read", "epv_set_options", "epv_get_options", "epv_phase_mode",
-    "epv_forward_simulate",
+    "epv_forward_simulate", "epv_copy_columns_async",
 ]
 
 

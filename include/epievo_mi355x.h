@@ -250,6 +250,11 @@ int epv_unpack_columns_dev(epv_ctx *ctx, uint64_t first, uint64_t count, const v
 int epv_device_of(const epv_ctx *ctx);
 /* the same between two contexts of ONE GPU (equal tree and capacity), without leaving the device */
 int epv_copy_columns(epv_ctx *src, uint64_t src_first, uint64_t count, epv_ctx *dst, uint64_t dst_first);
+/* ... without waiting on the host: packed on src's stream into half `slot` (0 / 1) of its staging
+ * buffer, unpacked on dst's stream behind an event; what the caller launches on dst's stream next
+ * (epv_reset) sees the columns.  One use of a (src, slot) pair per refresh. */
+int epv_copy_columns_async(epv_ctx *src, uint64_t src_first, uint64_t count, epv_ctx *dst, uint64_t dst_first,
+                           int slot);
 
 /* ---- several shards on one GPU (new; the reference is single-process).  Two or three
  * contexts on one device, each owning a contiguous range of 256-aligned site blocks plus
