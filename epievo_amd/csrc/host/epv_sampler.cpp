@@ -587,9 +587,17 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
         epv_ctx *c = parts_[s.part0].ctx;
         check_on(c, epv_blocks_to_rows(c, static_cast<const double *>(s.d_blocks), s.n_blocks, batch, row_blocks_,
                                        static_cast<double *>(s.d_rows)), "epv_blocks_to_rows");
-        uint64_t acc_slot = 0;
-        for (size_t p = s.part0; p < s.part1; ++p) acc_slot += acc[p];
-        check_on(c, epv_dev_write(c, static_cast<double *>(s.d_rows) + max_rows_ * row_words, &acc_slot, sizeof acc_slot),
+        // the tail of the piece: the slot's accept count, and the jump capacity of its contexts
+        // (a slot that absorbed an overflow widened its slots: every slot of the run must follow
+        // before the next halo exchange, whose column size depends on it)
+        uint64_t tail[2] = {0, 0};
+        for (size_t p = s.part0; p < s.part1; ++p) {
+          tail[0] += acc[p];
+          uint32_t cap = 0;
+          check_on(parts_[p].ctx, epv_get_capacity(parts_[p].ctx, &cap), "epv_get_capacity");
+          tail[1] = std::max<uint64_t>(tail[1], cap);
+        }
+        check_on(c, epv_dev_write(c, static_cast<double *>(s.d_rows) + max_rows_ * row_words, tail, sizeof tail),
                  "epv_dev_write");
       }
       if (epv_comm_group_start() != EPV_OK) throw std::runtime_error("epv_comm_group_start failed");
@@ -601,11 +609,18 @@ void SingleSiteSampler::run_mcmc(uint64_t seed, uint64_t em_iteration,
       check(epv_reduce_gathered_rows(ctx_, static_cast<const double *>(slots_[0].d_gather), (uint32_t)world_, max_rows_, piece,
                                      rows_of_slot_.data(), batch, 1, Jf.data(), Df.data()), "epv_reduce_gathered_rows");
       n_acc = 0;
+      uint64_t cap_all = 0;
       for (size_t g = 0; g < world_; ++g) {
-        uint64_t v = 0;
-        check(epv_dev_read(ctx_, &v, static_cast<const double *>(slots_[0].d_gather) + g * piece + max_rows_ * row_words, sizeof v),
+        uint64_t v[2] = {0, 0};
+        check(epv_dev_read(ctx_, v, static_cast<const double *>(slots_[0].d_gather) + g * piece + max_rows_ * row_words, sizeof v),
               "epv_dev_read");
-        n_acc += v;
+        n_acc += v[0];
+        cap_all = std::max(cap_all, v[1]);
+      }
+      for (Part &q : parts_) {     // (slots in other processes may have grown)
+        uint32_t cap = 0;
+        check_on(q.ctx, epv_get_capacity(q.ctx, &cap), "epv_get_capacity");
+        if (cap < cap_all) check_on(q.ctx, epv_set_capacity(q.ctx, (uint32_t)cap_all), "epv_set_capacity");
       }
     }
   }

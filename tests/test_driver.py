@@ -110,3 +110,25 @@ def test_bench_under_a_launcher_joins_by_rank():
     d = _bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--sites", "200000", "--no-cpu-baseline",
                 "--no-reference-leg"], env)
     assert d["n_gpus"] == 1 and d["config"]["launch"].startswith("torch.distributed.run")
+
+
+@pytest.mark.gpu
+def test_cpp_driver_slots_agree_on_a_grown_capacity(monkeypatch):
+    """a slot that absorbs a capacity overflow widens its jump slots; the width rides in the tail of
+    the statistics all-gather and every slot follows before the next halo exchange (whose column
+    size depends on it) -- also across processes, where the slots cannot look at each other"""
+    from epievo_amd import driver
+    monkeypatch.setenv("EPV_ROW_BLOCKS", "4")
+    monkeypatch.setenv("EPV_CONTEXTS_PER_GPU", "1")
+    model, tree, fp = simulate("pair", 30000, seed=2)          # T = 1: ~1 jump per path, up to ~10
+    cap0 = int(fp.counts().max())
+    s = driver.CppSampler(1, 2, devices=[0, 0, 0], capacity=cap0)
+    s.reset(model, tree, fp)
+    for it in range(4):                                        # overflows happen, are absorbed, the run goes on
+        if it:
+            s.reset(model)
+        J, D, acc = s.run_mcmc(7, it)
+        assert np.all(np.isfinite(D)) and 0.3 < acc <= 1.0
+    p = s.paths()
+    assert p.n_sites == fp.n_sites and p.counts().max() <= 2047
+    s.close()
