@@ -115,6 +115,11 @@ __device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long l
 #ifndef EPV_PROPOSE2_WAVES
 #define EPV_PROPOSE2_WAVES 3
 #endif
+// the fused phase emits its segment / branch tasks in one dense pass behind the node loop (1) or, as the
+// separate kernels do, node by node inside it (0; A/B runs)
+#ifndef EPV_FUSED_DENSE_EMIT
+#define EPV_FUSED_DENSE_EMIT 1
+#endif
 
 // -DEPV_P2_PROFILE: wave-time per section of the kernel, read back by tools/p2_profile.py
 #ifdef EPV_P2_PROFILE
@@ -480,6 +485,16 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         hrec0 = hcur;
         if (K >= 2u) hcur += K;
         if (!FUSED && (K & 63u) && !clean) states[(K - 1u) >> 6] = word;   // only a dirty branch is read back
+#if EPV_FUSED_DENSE_EMIT
+        // FUSED: proposal end state for the children (bit 31); "dirty" (bit 30) and the branch's first
+        // heavy record (bits 14..27) for the emission pass behind this loop, which gives every dirty
+        // (site, branch) pair its own lane; the sampled end states of a heavy branch wait in the
+        // slot of its first record's end-state uniform, which has been used
+        if (FUSED) {
+          regA[node * 64u + lane] = off | (prev << 31) | (clean ? 0u : 1u << 30) | (K >= 2u ? hrec0 << 14 : 0u);
+          if (!clean && K >= 2u) list[(size_t)hrec0 * HREC + 6u] = epv_u2d(w64);
+        } else
+#endif
         regA[node * 64u + lane] = off | (prev << 31);  // proposal end state for the children
         // the proposal's meta word (start state, no jumps yet; the fused phase's assembly adds the
         // count) takes the place of the current path's, which this lane has just read for the last
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         trip_b = 4u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT);
       }
       bool old_list = dirty_b;
-      if (SEG) {
+      if (SEG && !(FUSED && EPV_FUSED_DENSE_EMIT)) {
         // ---- dirty SEGMENTS onto the segment list (one lane each in epv_seg_search_kernel) and the
         //      branch onto the assemble list: one atomic per wave and node reserves both ranges.
         //      A branch with more than 64 segments, or one that finds the lists full, takes the
@@ -605,6 +620,102 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
       if (am && lane == 0)
         atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_ACCEPT, shard)], (unsigned long long)__popcll(am));
     }
+#if EPV_FUSED_DENSE_EMIT
+    if (FUSED) {
+      // ---- 6. the dirty (site, branch) pairs of this round, ONE LANE EACH: their dirty segments
+      //      onto the wave's segment list, the branch onto its assemble list.  (Doing this inside the
+      //      node loop cost two wave scans and ~130 instructions per node for the one lane in
+      //      fourteen that had a dirty branch there.)  The pair list lives in the Felsenstein records
+      //      of this round, which are dead now; everything a pair needs is in the node table, the
+      //      staged meta words and the heavy records.
+      uint32_t *plist = reinterpret_cast<uint32_t *>(pool);
+      uint32_t npair = 0u;
+      if (run)
+        for (uint32_t node = 1u; node < S.N; ++node) npair += (regA[node * 64u + lane] >> 30) & 1u;
+      const uint32_t inclP = wave_incl_scan_u32(npair);
+      const uint32_t totP = epv_bcast(inclP, 63);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (npair) {
+        uint32_t at = inclP - npair;
+        for (uint32_t node = 1u; node < S.N; ++node)
+          if ((regA[node * 64u + lane] >> 30) & 1u) plist[at++] = (uint32_t)lane | (node << 6);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t site_lane0 = site - 3u * (uint64_t)lane;
+      EpvSegTask *segs_w = F.segs + f_wave * F.seg_cap;
+      unsigned long long *btl = F.bt + f_wave * F.bt_cap;
+      uint32_t *bfl = F.bfirst + f_wave * F.bt_cap;
+      for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
+        const uint32_t pidx = p0 + (uint32_t)lane;
+        const bool act = pidx < totP;
+        const uint32_t pr = act ? plist[pidx] : 0u;
+        const uint32_t owner = pr & 63u, node = act ? pr >> 6 : 1u, b = node - 1u;
+        const uint32_t selM_o = (uint32_t)__shfl((int)selM, (int)owner);
+        const uint32_t ra = regA[node * 64u + owner];
+        const uint32_t end_b = ra >> 31, hrec0 = (ra >> 14) & 0x3fffu;
+        const uint32_t st_b = (uint32_t)(s_meta[(2u * B + b) * 64u + owner] >> EPV_INIT_SHIFT);
+        const uint32_t mL = s_meta[(0u * B + b) * 64u + owner], mR = s_meta[(1u * B + b) * 64u + owner];
+        const uint32_t Kb = (mL & EPV_NJ_MASK) + (mR & EPV_NJ_MASK) + 1u;
+        // which segments are dirty (trial 1 does not settle them)
+        unsigned long long w64 = end_b, dmask = 1ull;
+        uint32_t nds = act ? 1u : 0u;
+        if (act && Kb >= 2u) {
+          w64 = epv_d2u(list[(size_t)hrec0 * HREC + 6u]);
+          dmask = 0ull;
+          nds = 0u;
+          uint32_t prev = st_b;
+          for (uint32_t k = 0; k < Kb; ++k) {
+            const double *hr = list + (size_t)(hrec0 + k) * HREC;
+            const uint32_t sampled = (uint32_t)(w64 >> k) & 1u;
+            const bool seg_clean = (sampled == prev) && (1.0 - hr[7] < (prev ? hr[5] : hr[4]));
+            if (!seg_clean) { dmask |= 1ull << k; ++nds; }
+            prev = sampled;
+          }
+        }
+        const uint32_t inclS = wave_incl_scan_u32(nds);
+        const uint32_t totS = epv_bcast(inclS, 63);
+        if (act) {
+          const uint64_t osite = site_lane0 + 3u * (uint64_t)owner;
+          const uint64_t i0 = (uint64_t)f_nseg + (inclS - nds), j0 = (uint64_t)f_nbt + (uint32_t)lane;
+          btl[j0] = osite | ((unsigned long long)b << 40) | ((unsigned long long)nds << 52) | ((unsigned long long)end_b << 59) |
+                    ((unsigned long long)st_b << 60) | ((unsigned long long)(selM_o ^ 1u) << 61);
+          bfl[j0] = (uint32_t)i0;
+          uint32_t prev = st_b;
+          double tp = 0.0;     // running sum of the segment lengths (SingleSiteSampler.cpp:218)
+          uint64_t at = i0;
+          for (uint32_t k = 0; k < Kb; ++k) {
+            const uint32_t sampled = (uint32_t)(w64 >> k) & 1u;
+            double len;
+            uint32_t trip0;
+            if (Kb == 1u) {
+              len = s_blen[node];
+              trip0 = 4u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT);
+            } else {
+              const double *hr = list + (size_t)(hrec0 + k) * HREC;
+              len = hr[LEN_AT];
+              trip0 = (uint32_t)epv_d2u(hr[INFO_AT]) & 7u;
+            }
+            if ((dmask >> k) & 1ull) {
+              EpvSegTask t;
+              t.w0 = osite | ((unsigned long long)node << 40) | ((unsigned long long)k << 52);
+              t.len = len;
+              t.start = tp;
+              t.w3 = prev | (sampled << 1) | (trip0 << 2);
+              segs_w[at++] = t;
+            }
+            tp += len;
+            prev = sampled;
+          }
+        }
+        f_nseg += totS;
+        f_nbt += (totP - p0 < 64u) ? totP - p0 : 64u;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();     // the pool goes to the next round's records
+    }
+#endif
     pending = pending && !run;
     P2_MARK(6);
   }
