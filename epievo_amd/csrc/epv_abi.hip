@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -82,6 +83,7 @@ struct epv_ctx {
   uint64_t fused_waves = 0;      // waves the lists are allocated for
   uint32_t tasks_per_wave = 0;   // epv_mh_jumps_kernel: lanes of a wave that own a task (0 = by workload)
   double kbar = 0.0;  // mean jumps per (site, branch) of the uploaded paths
+  double fwd_alloc_ms = 0.0, fwd_sim_ms = 0.0;   // epv_forward_simulate: device memory management / the simulation itself
   size_t mh_lds = 0;
   // counters / timing
   uint64_t n_sweeps = 0, tot_overflow = 0, tot_coop = 0;
@@ -816,6 +818,7 @@ EPV_API int epv_forward_simulate(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
   if (n_sites < 3 || n_sites > 0xffffffffull) return fail(c, EPV_ERR_ARG, "bad number of sites");
   if (capacity == 0) capacity = 16u;
   if (capacity > EPV_MAX_CAP) capacity = EPV_MAX_CAP;
+  const auto t_begin = std::chrono::steady_clock::now();
   int rc = alloc_paths(c, n_sites, capacity, 0);
   if (rc) return rc;
   const uint64_t n = n_sites, N = c->S.N;
@@ -829,8 +832,10 @@ EPV_API int epv_forward_simulate(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
   HIP_TRY(c, k0.alloc(n)); HIP_TRY(c, k1.alloc(n));
   HIP_TRY(c, t0.alloc(n)); HIP_TRY(c, t1.alloc(n));
   HIP_TRY(c, endv.alloc(N * n));
-  HIP_TRY(c, info.alloc(2));
+  HIP_TRY(c, info.alloc(3));
   F.st[0] = st0.p; F.st[1] = st1.p; F.k[0] = k0.p; F.k[1] = k1.p; F.t[0] = t0.p; F.t[1] = t1.p; F.end = endv.p;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const auto t_alloc = std::chrono::steady_clock::now();
   F.lam_max = c->model.rates[0];
   for (int i = 1; i < 8; ++i) F.lam_max = std::max(F.lam_max, c->model.rates[i]);
   for (int i = 0; i < 8; ++i) F.pacc[i] = c->model.rates[i] / F.lam_max;
@@ -850,19 +855,21 @@ EPV_API int epv_forward_simulate(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
   // tiles of EPV_FWD_THREADS sites with `halo` redundant ones on each side, `rounds` rounds a launch
   const uint32_t halo = 16u, rounds = 64u, own_w = EPV_FWD_THREADS - 2u * halo;
   const unsigned tiles = (unsigned)((n + own_w - 1u) / own_w);
-  unsigned long long h_info[2] = {0ull, 0ull};
+  unsigned long long h_info[3] = {0ull, 0ull, 0ull};
+  uint64_t tot = 0;
   for (uint32_t node = 1; node < N; ++node) {
     uint32_t p = 0u;
     hipLaunchKernelGGL(epv_fwd_begin_kernel, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, c->stream, c->S, F, node,
                        c->parent[node], seed_lo, seed_hi, p);
     for (uint32_t launch = 0;; ++launch) {
-      HIP_TRY(c, hipMemsetAsync(info.p, 0, 2 * sizeof(unsigned long long), c->stream));
+      HIP_TRY(c, hipMemsetAsync(info.p, 0, 3 * sizeof(unsigned long long), c->stream));
       hipLaunchKernelGGL(epv_fwd_rounds_kernel, dim3(tiles), dim3(EPV_FWD_THREADS), 0, c->stream, c->S, F, node,
                          c->blen[node], seed_lo, seed_hi, p, halo, rounds, info.p);
       HIP_TRY(c, hipGetLastError());
       HIP_TRY(c, hipMemcpyAsync(h_info, info.p, sizeof h_info, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       p ^= 1u;
+      tot += h_info[2];
       if (h_info[1]) {
         char buf[160];
         std::snprintf(buf, sizeof buf, "forward simulation: %llu paths of node %u need more than %u jump slots; "
@@ -876,11 +883,19 @@ EPV_API int epv_forward_simulate(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
   }
   c->have_paths = true;
   c->have_reset = false;
-  uint64_t tot = 0;
-  if ((rc = epv_paths_total_jumps(c, &tot))) return rc;
   if (total_jumps) *total_jumps = tot;
   c->kbar = (double)tot / (double)(c->S.B * n);
+  const auto t_end = std::chrono::steady_clock::now();
+  c->fwd_alloc_ms = std::chrono::duration<double, std::milli>(t_alloc - t_begin).count();
+  c->fwd_sim_ms = std::chrono::duration<double, std::milli>(t_end - t_alloc).count();
   { int prc = plan_mh(c); return prc ? prc : plan_p2(c); }
+}
+
+EPV_API int epv_forward_last_ms(epv_ctx *c, double *alloc_ms, double *simulate_ms) {
+  if (!c || !alloc_ms || !simulate_ms) return EPV_ERR_ARG;
+  *alloc_ms = c->fwd_alloc_ms;
+  *simulate_ms = c->fwd_sim_ms;
+  return EPV_OK;
 }
 
 static int finish_mcmc(epv_ctx *c, uint64_t *n_accepted, uint64_t acc_base);

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void epv_fwd_begin_kernel(EpvDev S, EpvFwd F, 
 
 // ---- up to `rounds` rounds of local-minimum resolution on tiles of blockDim sites, of which the
 // inner blockDim - 2 halo are owned (written back); reads front buffer p, writes 1 - p.
-// info[0] += owned sites with a candidate left, info[1] += capacity overflows
+// info[0] += owned sites with a candidate left, info[1] += capacity overflows, info[2] += flips of owned sites
 #define EPV_FWD_THREADS 512
 __global__ __launch_bounds__(EPV_FWD_THREADS) void epv_fwd_rounds_kernel(EpvDev S, EpvFwd F, uint32_t node, double T,
                                                                           uint32_t seed_lo, uint32_t seed_hi, uint32_t p,
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(EPV_FWD_THREADS) void epv_fwd_rounds_kernel(EpvDev 
   s_t[i] = t;
   s_st[i] = (uint8_t)st;
   bool ovf = false;
+  uint32_t flips = 0u;
   const bool inner = i > 0u && i + 1u < W;      // the tile's two edge sites only wait
   for (uint32_t r = 0; r < rounds; ++r) {
     __syncthreads();
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(EPV_FWD_THREADS) void epv_fwd_rounds_kernel(EpvDev 
         if (owned) {
           if (cnt < S.C) jp[(uint64_t)cnt * S.n] = t; else ovf = true;
           ++cnt;
+          ++flips;
         }
       }
       ++k;
@@ -177,6 +179,9 @@ __global__ __launch_bounds__(EPV_FWD_THREADS) void epv_fwd_rounds_kernel(EpvDev 
     if (pend) atomicAdd(&info[0], (unsigned long long)pend);
     if (novf) atomicAdd(&info[1], (unsigned long long)novf);
   }
+  // one atomic per wave for the flips (the total of the histories' jumps: no pass over them afterwards)
+  const uint32_t wsum = epv_bcast(wave_incl_scan_u32(flips), 63);
+  if (epv_lane() == 0 && wsum) atomicAdd(&info[2], (unsigned long long)wsum);
 }
 
 #endif

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "epv_run_mcmc_blocks", "epv_reduce_blocks", "epv_get_counters", "epv_kernel_time_ms",
     "epv_set_timing", "epv_pack_columns_dev", "epv_unpack_columns_dev", "epv_device_of",
     "epv_blocks_to_rows", "epv_reduce_rows", "epv_reduce_gathered_rows", "epv_dev_write", "epv_dev_read", "epv_set_options", "epv_get_options", "epv_phase_mode",
-    "epv_forward_simulate", "epv_copy_columns_async",
+    "epv_forward_simulate", "epv_forward_last_ms", "epv_copy_columns_async",
 ]
 
 
@@ -111,6 +111,7 @@ def lib():
         L.epv_set_options.argtypes = [vp, C.c_uint32]
         L.epv_forward_simulate.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32,
                                            C.POINTER(C.c_uint64)]
+        L.epv_forward_last_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.epv_get_options.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.epv_phase_mode.argtypes = [vp, C.POINTER(C.c_uint32)]
         L.epv_dev_write.argtypes = [vp, vp, vp, C.c_uint64]
@@ -261,6 +262,12 @@ class DeviceSampler:
                 continue
             self._ck(rc)
             return int(tot.value)
+
+    def forward_last_ms(self):
+        """(device memory management, simulation) wall clock of the last forward_simulate, ms"""
+        a, b = C.c_double(0), C.c_double(0)
+        self._ck(self.L.epv_forward_last_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def indep_expectation(self, rates):
         r = np.ascontiguousarray(rates, np.float64)

@@ -151,6 +151,10 @@ int epv_init_paths_indep(epv_ctx *ctx, uint64_t n_sites, const uint8_t *root_sta
  * when a path needs more (call again with a larger capacity: same histories). */
 int epv_forward_simulate(epv_ctx *ctx, uint64_t n_sites, const uint8_t *root_states, uint64_t seed,
                          uint32_t capacity, uint64_t *total_jumps);
+/* wall clock of the last epv_forward_simulate: device memory management (freeing the previous paths,
+ * allocating the new ones: tens of GB at n = 1e7) and the simulation itself (root sequence, every
+ * branch, the count of the jumps) */
+int epv_forward_last_ms(epv_ctx *ctx, double *alloc_ms, double *simulate_ms);
 
 /* ---- the site-independent 2-rate model of epievo_initialization (IndepSite.hpp:40-72);
  * rates = {r0, r1}; J/D laid out [(b-1)*2 + state].
