@@ -721,6 +721,7 @@ EPV_API int epv_set_model(epv_ctx *c, const double *triplet_rates, const double 
   }
   for (int i = 0; i < 4; ++i) c->model.T[i] = T[i];
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // (a kernel of epv_reset_async may still read the old constants)
   HIP_TRY(c, hipMemcpy(c->d_model, &c->model, sizeof(EpvModelConst), hipMemcpyHostToDevice));
   c->S.model = c->d_model;
   c->have_model = true;
@@ -1207,19 +1208,28 @@ EPV_API int epv_halo_phases_left(epv_ctx *c, uint64_t *phases) {
   return EPV_OK;
 }
 
-EPV_API int epv_reset(epv_ctx *c) {
+// the reset's launches without waiting for them: the MCMC calls that follow sit behind them on the
+// context's stream (an EM driver goes from reset straight into run_mcmc: the device need not idle
+// while the host finds that out)
+EPV_API int epv_reset_async(epv_ctx *c) {
   int rc = check_ready(c, false);
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->d_segtab) HIP_TRY(c, hipMalloc(&c->d_segtab, (size_t)4095u * 4u * 6u * sizeof(double)));
   hipLaunchKernelGGL(epv_reset_kernel, dim3((unsigned)((c->S.n + 255u) / 256u)), dim3(256),
                      const_lds_bytes(c->S.N), c->stream, c->S);
   // the single-segment matrices of every (branch, neighbour context): model and branch lengths
   // are fixed until the next reset
-  if (!c->d_segtab) HIP_TRY(c, hipMalloc(&c->d_segtab, (size_t)4095u * 4u * 6u * sizeof(double)));
   hipLaunchKernelGGL(epv_segtab_kernel, dim3((c->S.B * 4u + 63u) / 64u), dim3(64), 0, c->stream, c->S, c->d_segtab);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_reset = true;
+  return EPV_OK;
+}
+
+EPV_API int epv_reset(epv_ctx *c) {
+  int rc = epv_reset_async(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return EPV_OK;
 }
 

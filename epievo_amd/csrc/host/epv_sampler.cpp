@@ -505,16 +505,10 @@ void SingleSiteSampler::reset(const Model &m) {
   }
   for (Part &p : parts_) check_on(p.ctx, epv_set_model(p.ctx, m.rates.data(), m.T.data()), "epv_set_model");
   refresh_parts();
-  // the parts' cached likelihoods, each on its own stream from its own host thread
-  std::vector<std::string> errors(parts_.size());
-  ThreadGroup workers;
-  for (size_t i = 0; i < parts_.size(); ++i)
-    workers.spawn([this, i, &errors] {
-      try { check_on(parts_[i].ctx, epv_reset(parts_[i].ctx), "epv_reset"); }
-      catch (const std::exception &e) { errors[i] = e.what(); }
-    });
-  workers.join();
-  for (const std::string &e : errors) if (!e.empty()) throw std::runtime_error(e);
+  // the parts' cached likelihoods: launched on every part's stream, not waited for -- the MCMC calls
+  // that follow queue up behind them (reset -> run_mcmc is how the EM loop goes,
+  // epievo_est_params_histories.cpp:241-248), download() and the other readers synchronise anyway
+  for (Part &p : parts_) check_on(p.ctx, epv_reset_async(p.ctx), "epv_reset_async");
 }
 
 // words appended to a slot's rows in the all-gather: its accept count

@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "epv_create", "epv_destroy", "epv_last_error", "epv_set_tree", "epv_set_model",
     "epv_upload_paths", "epv_set_capacity", "epv_get_capacity", "epv_init_paths_indep", "epv_indep_expectation",
     "epv_indep_sufficient_statistics", "epv_indep_update_paths", "epv_set_global_length", "epv_set_update_range", "epv_set_halo",
-    "epv_halo_phases_left", "epv_reset", "epv_sweep",
+    "epv_halo_phases_left", "epv_reset", "epv_reset_async", "epv_sweep",
     "epv_sweep_phase", "epv_run_mcmc", "epv_run_mcmc_sums", "epv_get_sufficient_statistics", "epv_scale_jump_times",
     "epv_paths_total_jumps", "epv_download_paths", "epv_get_tri_llh", "epv_column_bytes",
     "epv_get_columns", "epv_put_columns", "epv_copy_columns", "epv_dev_alloc", "epv_dev_free",

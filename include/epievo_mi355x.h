@@ -193,6 +193,8 @@ int epv_halo_phases_left(epv_ctx *ctx, uint64_t *phases);
 /* SingleSiteSampler::reset (SingleSiteSampler.cpp:449-475): cache the complete-data
  * log-likelihood of every interior triple. */
 int epv_reset(epv_ctx *ctx);
+/* the same without waiting for the device: whatever is called next on the context runs behind it */
+int epv_reset_async(epv_ctx *ctx);
 
 /* n_sweeps x single_iteration (SingleSiteSampler.cpp:538-548) under the 3-colour
  * schedule; this is also the loop epievo_sim_pairwise.cpp:267-273 spells out by hand.
