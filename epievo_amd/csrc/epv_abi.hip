@@ -71,6 +71,12 @@ struct epv_ctx {
   double *d_gpool2 = nullptr;
   uint64_t gpool2_cap = 0;
   double *d_segtab = nullptr;    // [B][4][6] single-segment matrices, refreshed by epv_reset
+  // third proposal kernel (epv_propose3.h): large trees, where the record pool does not fit LDS
+  int use_p3 = -1;               // -1 = whenever the plan allows it, EPV_PROPOSE_V3=0/1 forces
+  bool p3 = false;               // decided by plan_p3 for the uploaded tree and paths
+  uint32_t p3_list_cap = 0, p3_qrows = 0, p3_levels = 0;
+  size_t p3_lds = 0;
+  uint32_t *d_nodetab = nullptr; // [N] parent | level | q row | leaf | last child (EPV_P3_*)
   uint32_t phase_parity = 0;     // accept lists are double-buffered by phase parity
   int use_seg = -1;              // segment-parallel jump kernels (epv_jumps2.h): -1 = by workload
                                  // (long branches, kbar >= 0.25), EPV_SEG_JUMPS=0/1 forces
@@ -268,6 +274,65 @@ int plan_p2(epv_ctx *c) {
   c->p2_pool = (uint32_t)rows;
   c->p2_list_cap = (uint32_t)list_cap;
   c->p2_lds = shared + c->p2_waves * per_wave_fixed;
+  return EPV_OK;
+}
+
+// launch shape of epv_mh_propose3_kernel, for trees whose record pool does not fit LDS: per wave a
+// 16-bit word per (node, lane) and a stack of partial products in LDS, q rows of the internal nodes
+// and the heavy-segment records in a slab of global memory
+int plan_p3(epv_ctx *c) {
+  c->p3 = false;
+  const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
+  if (c->use_p3 == 0 || !c->use_p2 || N > 64u || N < 2u) return EPV_OK;
+  if (c->use_p3 < 0 && !c->p2_gpool) return EPV_OK;     // the LDS pool is the better place while it fits
+  // per node: parent, depth, children; q rows for the internal nodes below the root
+  std::vector<uint32_t> depth(N, 0u), kids(N, 0u), tab(N, 0u);
+  uint32_t qrows = 0, levels = 0;
+  for (uint32_t node = 1; node < N; ++node) {
+    depth[node] = depth[c->parent[node]] + 1u;
+    ++kids[c->parent[node]];
+  }
+  for (uint32_t node = 1; node < N; ++node) {
+    const bool leaf = c->subtree[node] == 1u;
+    if (kids[node] > 2u) return EPV_OK;     // (a product of three partials does not commute bit for bit)
+    const uint32_t par = c->parent[node];
+    const bool last_child = node + c->subtree[node] == par + c->subtree[par];
+    uint32_t w = par | ((depth[node] - 1u) << 6) | ((leaf ? 1u : 0u) << 18) | ((last_child ? 1u : 0u) << 19);
+    if (!leaf) {
+      w |= qrows << 12;
+      ++qrows;
+      levels = std::max(levels, depth[node]);
+    }
+    tab[node] = w;
+  }
+  if (levels > 24u) return EPV_OK;          // a 1 KB stack level per depth: keep >= 2 waves per SIMD
+  const double lam = 2.0 * c->kbar;
+  const double heavy_per_branch = (1.0 + lam) - std::exp(-lam);
+  const uint64_t worst_heavy = (uint64_t)B * (2u * C + 1u);
+  // EPV_P3_MIN_LIST=1 (tests): one lane's worst case only, so that busy waves run in several rounds
+  static const bool min_list = std::getenv("EPV_P3_MIN_LIST") != nullptr;
+  const uint64_t list_cap = min_list ? worst_heavy : std::max<uint64_t>(worst_heavy, (uint64_t)(64.0 * B * heavy_per_branch * 1.5) + 64u);
+  if (list_cap >= (1ull << 20)) return EPV_OK;             // the pair word's record field
+  const uint64_t waves = ((c->S.phase_cap + 255u) / 256u) * 4u;
+  const uint64_t need = waves * ((uint64_t)qrows * 128u + list_cap * EPV_HREC_SHORT);
+  if (need * sizeof(double) > (24ull << 30)) return EPV_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (need > c->gpool2_cap) {
+    dfree(c->d_gpool2);
+    c->gpool2_cap = 0;
+    HIP_TRY(c, hipMalloc(&c->d_gpool2, need * sizeof(double)));
+    c->gpool2_cap = need;
+  }
+  if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 64u * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemcpy(c->d_nodetab, tab.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice));
+  const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * EPV_SEGTAB_DBL * 8u + (size_t)((N + 1u) / 2u) * 8u;
+  const size_t per_wave = ((size_t)N * 64u * 2u + 15u) / 16u * 16u + (size_t)std::max<uint32_t>(levels * 128u, EPV_P3_PCAP / 2u) * 8u;
+  c->p3_lds = shared + 4u * per_wave;
+  if (c->p3_lds > 160u * 1024u) return EPV_OK;
+  c->p3_list_cap = (uint32_t)list_cap;
+  c->p3_qrows = qrows;
+  c->p3_levels = levels;
+  c->p3 = true;
   return EPV_OK;
 }
 
@@ -479,7 +544,8 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   // more than its dense evaluation saves (16-leaf tree: 830 vs 676 us);
   // EPV_PROPOSE_V2_GLOBAL=1 forces it for A/B runs
   static const bool p2_global = std::getenv("EPV_PROPOSE_V2_GLOBAL") != nullptr;
-  const bool p2 = c->use_p2 && !refq && (!c->p2_gpool || p2_global);
+  const bool p3 = c->p3 && !refq;
+  const bool p2 = !p3 && c->use_p2 && !refq && (!c->p2_gpool || p2_global);
   uint32_t list_mode = 0;
   // segment-parallel jumps pay on long branches (single branch T = 1: +17 %, every segment is
   // dirty and needs several trials) and cost on short ones (tree.nwk: -12 %, one dirty segment in
@@ -508,7 +574,16 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   }
   const uint32_t seg_mode = (p2 && seg_jumps_on(c)) ? 1u : 0u;
   if (seg_mode) { const int src = ensure_seg_buffers(c); if (src) return src; }
-  if (p2) {
+  if (p3) {
+    // large tree: a 16-bit word per (node, lane) in LDS, q rows and heavy records in a slab (epv_propose3.h)
+    list_mode = 1u + (c->phase_parity & 1u);
+    const unsigned pb = (unsigned)((threads + 255u) / 256u);
+    hipLaunchKernelGGL(epv_mh_propose3_kernel<false>, dim3(pb), dim3(256), c->p3_lds, c->stream, c->S, (uint32_t)colour,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->p3_list_cap,
+                       c->p3_qrows, c->p3_levels, c->phase_parity & 1u, c->d_counters, c->d_gpool2, c->d_segtab,
+                       c->d_nodetab);
+    ++c->phase_parity;
+  } else if (p2) {
     list_mode = 1u + (c->phase_parity & 1u);
     const unsigned pt = 64u * c->p2_waves, pb = (unsigned)((threads + pt - 1u) / pt);
     auto kern = c->p2_gpool ? (seg_mode ? epv_mh_propose2_kernel<true, true, false> : epv_mh_propose2_kernel<true, false, false>)
@@ -618,6 +693,7 @@ EPV_API epv_ctx *epv_create(int device_id) {
   epv_ctx *c = new epv_ctx();
   c->device = device_id;
   if (const char *e = std::getenv("EPV_PROPOSE_V1")) c->use_p2 = std::atoi(e) == 0;
+  if (const char *e = std::getenv("EPV_PROPOSE_V3")) c->use_p3 = std::atoi(e) != 0 ? 1 : 0;
   if (const char *e = std::getenv("EPV_SEG_JUMPS")) c->use_seg = std::atoi(e) != 0 ? 1 : 0;
   if (const char *e = std::getenv("EPV_FUSED_PHASE")) c->use_fused = std::atoi(e) != 0 ? 1 : 0;
   if (const char *e = std::getenv("EPV_FUSED_MAX_WAVES")) { const long v = std::atol(e); if (v >= 0) c->fused_max_waves = (uint32_t)v; }
@@ -636,6 +712,8 @@ EPV_API epv_ctx *epv_create(int device_id) {
     return nullptr;
   }
   // the MH kernel asks for more dynamic LDS than the 64 KiB default
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose3_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, true, false>),
@@ -663,7 +741,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_sweep_tot); dfree(c->d_statscale); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_segtab);
+  dfree(c->d_counters); dfree(c->d_sweep_tot); dfree(c->d_statscale); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_segtab); dfree(c->d_nodetab);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   if (c->h_cnt_snap) (void)hipHostFree(c->h_cnt_snap);
   for (hipEvent_t &e : c->ev_copy) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -707,7 +785,7 @@ EPV_API int epv_set_tree(epv_ctx *c, int n_nodes, const uint32_t *parent_ids,
   c->S.blen = c->d_blen;
   c->have_tree = true;
   c->have_reset = false;
-  if (c->have_paths) { int rc = plan_mh(c); return rc ? rc : plan_p2(c); }
+  if (c->have_paths) { int rc = plan_mh(c); if (!rc) rc = plan_p2(c); return rc ? rc : plan_p3(c); }
   return EPV_OK;
 }
 
@@ -805,7 +883,7 @@ EPV_API int epv_upload_paths(epv_ctx *c, uint64_t n_sites, const uint8_t *init_s
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_paths = true;
   c->have_reset = false;
-  { int rc = plan_mh(c); return rc ? rc : plan_p2(c); }
+  { int rc = plan_mh(c); if (!rc) rc = plan_p2(c); return rc ? rc : plan_p3(c); }
 }
 
 // epievo_sim's forward simulation on the device (epv_forward.h): root sequence (given, or
@@ -889,7 +967,7 @@ EPV_API int epv_forward_simulate(epv_ctx *c, uint64_t n_sites, const uint8_t *ro
   const auto t_end = std::chrono::steady_clock::now();
   c->fwd_alloc_ms = std::chrono::duration<double, std::milli>(t_alloc - t_begin).count();
   c->fwd_sim_ms = std::chrono::duration<double, std::milli>(t_end - t_alloc).count();
-  { int prc = plan_mh(c); return prc ? prc : plan_p2(c); }
+  { int prc = plan_mh(c); if (!prc) prc = plan_p2(c); return prc ? prc : plan_p3(c); }
 }
 
 EPV_API int epv_forward_last_ms(epv_ctx *c, double *alloc_ms, double *simulate_ms) {
@@ -922,6 +1000,7 @@ EPV_API int epv_phase_mode(epv_ctx *c, uint32_t *mode) {
   const bool refq = c->S.flags & (EPV_FLAG_REFERENCE_PROPOSAL_RATIO | EPV_FLAG_SAMPLE_ROOT);
   static const bool p2_global = std::getenv("EPV_PROPOSE_V2_GLOBAL") != nullptr;
   const bool p2 = c->use_p2 && !refq && (!c->p2_gpool || p2_global);
+  if (c->p3 && !refq) { *mode = EPV_PHASE_V3; return EPV_OK; }
   *mode = !p2 ? EPV_PHASE_V1 : c->fused ? EPV_PHASE_FUSED : seg_jumps_on(c) ? EPV_PHASE_V2_SEGMENTS : EPV_PHASE_V2;
   return EPV_OK;
 }
@@ -970,7 +1049,7 @@ EPV_API int epv_set_capacity(epv_ctx *c, uint32_t capacity) {
   c->S.prop_states = ns.release();
   c->S.C = capacity;
   c->S.W = W;
-  { int rc2 = plan_mh(c); return rc2 ? rc2 : plan_p2(c); }
+  { int rc2 = plan_mh(c); if (!rc2) rc2 = plan_p2(c); return rc2 ? rc2 : plan_p3(c); }
 }
 
 EPV_API int epv_init_paths_indep(epv_ctx *c, uint64_t n_sites, const uint8_t *root_states,

@@ -122,7 +122,7 @@ int epv_get_options(epv_ctx *ctx, uint32_t *flags);
  *     epv_seg_search_kernel + epv_seg_assemble_kernel + accept (long branches), 3 = the fused phase:
  *     one epv_mh_propose2_kernel launch that also samples the jump times and accepts (launches of few
  *     waves).  No reference counterpart. */
-enum { EPV_PHASE_V1 = 0, EPV_PHASE_V2 = 1, EPV_PHASE_V2_SEGMENTS = 2, EPV_PHASE_FUSED = 3 };
+enum { EPV_PHASE_V1 = 0, EPV_PHASE_V2 = 1, EPV_PHASE_V2_SEGMENTS = 2, EPV_PHASE_FUSED = 3, EPV_PHASE_V3 = 4 };
 int epv_phase_mode(epv_ctx *ctx, uint32_t *mode);
 
 /* initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device, for the

@@ -257,6 +257,13 @@ _SEPARATE = {"EPV_FUSED_PHASE": "0"}      # small launches take the fused phase 
                                        ("bal16", 2000, dict(_SEPARATE, EPV_PROPOSE_V2_GLOBAL="1", EPV_FORCE_GLOBAL_POOL="1")),
                                        ("tree", 5000, dict(_SEPARATE, EPV_FORCE_GLOBAL_POOL="1", EPV_PROPOSE_V2_GLOBAL="1",
                                                            EPV_SEG_JUMPS="1")),
+                                       ("bal16", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="0")),
+                                       ("bal16", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
+                                       ("bal16", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="1", EPV_P3_MIN_LIST="1")),
+                                       ("tree", 20011, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
+                                       ("cat6", 3000, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
+                                       ("star4", 3000, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
+                                       ("pair", 9000, dict(_SEPARATE, EPV_PROPOSE_V3="1", EPV_P3_MIN_LIST="1")),
                                        ("tree", 20011, {"EPV_FUSED_PHASE": "1"}), ("pair", 9000, {"EPV_FUSED_PHASE": "1"}),
                                        ("cat6", 3000, {"EPV_FUSED_PHASE": "1"}),
                                        ("tree", 20011, {"EPV_FUSED_PHASE": "1", "EPV_ACCEPT_NO_CACHE": "1"})])
@@ -302,7 +309,7 @@ print("ok")
 
 def test_phase_mode_follows_the_workload():
     """epv_phase_mode (include/epievo_mi355x.h): small launches take the fused colour phase, the
-    reference's proposal arithmetic and large trees the first proposal kernel, a large capacity
+    reference's proposal arithmetic the first proposal kernel, large trees the third, a large capacity
     (more than 64 segments per branch possible) the separate kernels; the choice never changes a
     number (test_every_kernel_path_is_bit_exact forces each against rung B)"""
     from common import simulate
@@ -322,7 +329,9 @@ def test_phase_mode_follows_the_workload():
     assert n1 == n0 and np.array_equal(J1, J0) and np.array_equal(D1, D0)
     model, tree, fp = simulate("bal16", 2000, seed=6)
     d3 = DeviceSampler(0); d3.set_tree(tree); d3.set_model(model); d3.upload_paths(fp, 16); d3.reset()
-    assert d3.phase_mode() == 0             # record pool in global memory: first proposal kernel
+    assert d3.phase_mode() == 4             # record pool does not fit LDS: the large-tree proposal kernel
+    d3.set_options(reference_proposal_ratio=True)
+    assert d3.phase_mode() == 0             # the reference's sums: first proposal kernel, pool in global memory
 
 
 @pytest.mark.parametrize("scale,n", [(4.0, 30000), (3.0, 20000)])
