@@ -314,7 +314,7 @@ int plan_p3(epv_ctx *c) {
   const uint64_t list_cap = min_list ? worst_heavy : std::max<uint64_t>(worst_heavy, (uint64_t)(64.0 * B * heavy_per_branch * 1.5) + 64u);
   if (list_cap >= (1ull << 20)) return EPV_OK;             // the pair word's record field
   const uint64_t waves = ((c->S.phase_cap + 255u) / 256u) * 4u;
-  const uint64_t need = waves * ((uint64_t)qrows * 128u + list_cap * EPV_HREC_SHORT);
+  const uint64_t need = waves * ((uint64_t)EPV_P3_PCAP + (uint64_t)qrows * 128u + list_cap * EPV_HREC_SHORT);
   if (need * sizeof(double) > (24ull << 30)) return EPV_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   if (need > c->gpool2_cap) {
@@ -326,7 +326,7 @@ int plan_p3(epv_ctx *c) {
   if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 64u * sizeof(uint32_t)));
   HIP_TRY(c, hipMemcpy(c->d_nodetab, tab.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice));
   const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * EPV_SEGTAB_DBL * 8u + (size_t)((N + 1u) / 2u) * 8u;
-  const size_t per_wave = ((size_t)N * 64u * 2u + 15u) / 16u * 16u + (size_t)std::max<uint32_t>(levels * 128u, EPV_P3_PCAP / 2u) * 8u;
+  const size_t per_wave = ((size_t)N * 64u * 2u + 15u) / 16u * 16u + (size_t)levels * 128u * 8u;
   c->p3_lds = shared + 4u * per_wave;
   if (c->p3_lds > 160u * 1024u) return EPV_OK;
   c->p3_list_cap = (uint32_t)list_cap;

@@ -42,8 +42,11 @@
 
 // s_ent[node * 64 + lane]: bit 0 right neighbour's start state, 1 left neighbour's, 2 this path's,
 // 3 parity of this path's jump count, 4 this path has jumps, 5 heavy (a neighbour jumps on the
-// branch), 6 the proposal's end state (downward pass), bits 8..15 min(K - 1, 255)
+// branch), 6 the proposal's end state (downward pass), 7 more than 64 segments (the sequential
+// loop of the downward pass), bits 8..11 min(K - 1, 15), bits 12..15 of a heavy branch: end state
+// and "clean" for start state 0, the same for start state 1 (the pair pass behind pruning)
 #define EPV_P3_HEAVY 32u
+#define EPV_P3_SLOW 128u
 
 template <bool DUMMY>
 __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
@@ -52,12 +55,15 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
     uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab, const uint32_t *nodetab) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   constexpr uint32_t HREC = EPV_HREC_SHORT, LEN_AT = HREC - 2u, INFO_AT = HREC - 1u;
+#ifdef EPV_P2_PROFILE
+  unsigned long long t_acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
   const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
   const uint32_t tab_dbl = S.B * 4u * EPV_SEGTAB_DBL;
   const uint32_t node_dbl = (S.N + 1u) / 2u;
   const uint32_t ent_dbl = (S.N * 64u * (uint32_t)sizeof(uint16_t) + 15u) / 16u * 2u;
-  // the stack of partial products (pruning) shares its space with the pair list (listing)
-  const uint32_t stk_dbl = levels * 128u > EPV_P3_PCAP / 2u ? levels * 128u : EPV_P3_PCAP / 2u;
+  const uint32_t stk_dbl = levels * 128u;     // the stack of partial products (pruning)
   const uint32_t wave_id = threadIdx.x >> 6;
   const uint32_t wave_dbl = ent_dbl + stk_dbl;
   double *s_const = s_mem;
@@ -66,11 +72,13 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
   double *s_wave = s_mem + const_dbl + tab_dbl + node_dbl + (size_t)wave_id * wave_dbl;
   uint16_t *s_ent = reinterpret_cast<uint16_t *>(s_wave);
   double *s_stk = s_wave + ent_dbl;
-  uint32_t *plist = reinterpret_cast<uint32_t *>(s_stk);
   const int lane = epv_lane();
   const uint32_t my_shard = (blockIdx.x * (blockDim.x >> 6) + wave_id) & (EPV_SHARDS - 1u);
-  // per-wave slab: q rows of 64 interleaved records, then the flat heavy list
-  double *qrows = gpool + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_id) * ((size_t)n_qrows * 128u + (size_t)list_cap * HREC);
+  // per-wave slab: the pair list, q rows of 64 interleaved records, the flat heavy list
+  double *slab = gpool + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_id) *
+                             ((size_t)EPV_P3_PCAP + (size_t)n_qrows * 128u + (size_t)list_cap * HREC);
+  unsigned long long *plist = reinterpret_cast<unsigned long long *>(slab);
+  double *qrows = slab + EPV_P3_PCAP;
   double *list = qrows + (size_t)n_qrows * 128u;
   const uint64_t gfirst = S.g0 + first;
   const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
@@ -106,19 +114,20 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
       const uint32_t K = (mL & EPV_NJ_MASK) + (mR & EPV_NJ_MASK) + 1u;
       const uint32_t e = (mR >> EPV_INIT_SHIFT) | ((mL >> EPV_INIT_SHIFT) << 1) | ((mM >> EPV_INIT_SHIFT) << 2) |
                          ((mM & 1u) << 3) | ((mM & EPV_NJ_MASK) ? 16u : 0u) | (K >= 2u ? EPV_P3_HEAVY : 0u) |
-                         ((K - 1u < 255u ? K - 1u : 255u) << 8);
+                         (K > 64u ? EPV_P3_SLOW : 0u) | ((K - 1u < 15u ? K - 1u : 15u) << 8);
       s_ent[(b + 1u) * 64u + lane] = (uint16_t)e;
       if (K >= 2u) { heavy += K; ++n_pairs; }
     }
   }
-  // segments of the branch above `node` (the word holds it up to 255; beyond, from the meta words)
+  // segments of the branch above `node` (the word holds it up to 15; beyond, from the meta words)
   auto segments_of = [&](uint32_t e, uint32_t node) __attribute__((always_inline)) -> uint32_t {
-    const uint32_t k8 = e >> 8;
-    if (k8 < 255u) return k8 + 1u;
+    const uint32_t k4 = (e >> 8) & 15u;
+    if (k4 < 15u) return k4 + 1u;
     return (uint32_t)(S.meta[mbaseL + (uint64_t)(node - 1u) * n] & EPV_NJ_MASK) +
            (uint32_t)(S.meta[mbaseR + (uint64_t)(node - 1u) * n] & EPV_NJ_MASK) + 1u;
   };
 
+  P2_MARK(0);
   bool pending = valid;
   while (__any(pending)) {
     const uint32_t wantH = pending ? heavy : 0u, wantP = pending ? n_pairs : 0u;
@@ -130,36 +139,62 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
     const uint32_t totH = rmask ? epv_bcast(inclH, hi_lane) : 0u, totP = rmask ? epv_bcast(inclP, hi_lane) : 0u;
     const uint32_t hbase = inclH - wantH;
 
-    // ---- 1. the heavy (lane, node) pairs: lane | node << 6 | first record << 12
+    P2_MARK(1);
+    // ---- 1. the heavy (lane, node) pairs: lane | node << 6 | segments << 12 | first record << 32
     if (run && n_pairs) {
       uint32_t hcur = hbase, at = inclP - n_pairs;
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t e = s_ent[node * 64u + lane];
         if (!(e & EPV_P3_HEAVY)) continue;
-        plist[at++] = (uint32_t)lane | (node << 6) | (hcur << 12);
-        hcur += segments_of(e, node);
+        const uint32_t K = segments_of(e, node);
+        plist[at++] = (unsigned long long)lane | ((unsigned long long)node << 6) | ((unsigned long long)K << 12) |
+                      ((unsigned long long)hcur << 32);
+        hcur += K;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- 2. one pair per lane: forward merge of the neighbours' jumps (Segment.cpp:35-79) into the
-    //         records' length and address fields
-    for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
-      const uint32_t pidx = p0 + (uint32_t)lane;
-      const uint32_t pr = pidx < totP ? plist[pidx] : 0u;
-      const uint32_t owner = pr & 63u;
-      const uint64_t jl = (uint64_t)__shfl((uint32_t)jbaseL, (int)owner) | ((uint64_t)__shfl((uint32_t)(jbaseL >> 32), (int)owner) << 32);
-      const uint64_t jr = (uint64_t)__shfl((uint32_t)jbaseR, (int)owner) | ((uint64_t)__shfl((uint32_t)(jbaseR >> 32), (int)owner) << 32);
-      const uint64_t ml = (uint64_t)__shfl((uint32_t)mbaseL, (int)owner) | ((uint64_t)__shfl((uint32_t)(mbaseL >> 32), (int)owner) << 32);
-      const uint64_t mr = (uint64_t)__shfl((uint32_t)mbaseR, (int)owner) | ((uint64_t)__shfl((uint32_t)(mbaseR >> 32), (int)owner) << 32);
-      if (pidx < totP) {
-        const uint32_t node = (pr >> 6) & 63u, hcur = pr >> 12, b = node - 1u;
-        const uint32_t cL = S.meta[ml + (uint64_t)b * n], cR = S.meta[mr + (uint64_t)b * n];
-        const uint32_t nL = cL & EPV_NJ_MASK, nR = cR & EPV_NJ_MASK, K = nL + nR + 1u;
-        const double *Lj = S.jumps + jl + (uint64_t)b * Cn, *Rj = S.jumps + jr + (uint64_t)b * Cn;
-        uint32_t trip0 = 4u * (cL >> EPV_INIT_SHIFT) + (cR >> EPV_INIT_SHIFT), i = 0, j = 0;
+    //         records' length and address fields.  Three passes of pairs at a time, stage by stage, so
+    //         that their round trips (pair word -> meta words -> first jumps) overlap
+    for (uint32_t p0 = 0; p0 < totP; p0 += 3u * 64u) {
+      constexpr int NP = 3;
+      unsigned long long pr[NP];
+      bool act[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const uint32_t pidx = p0 + 64u * (uint32_t)q + (uint32_t)lane;
+        act[q] = pidx < totP;
+        pr[q] = act[q] ? plist[pidx] : 0ull;
+      }
+      const double *Lj[NP], *Rj[NP];
+      uint32_t cL[NP], cR[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const uint32_t owner = (uint32_t)pr[q] & 63u, b = ((((uint32_t)pr[q] >> 6) & 63u) - 1u) & 63u;
+        const uint64_t jl = (uint64_t)__shfl((uint32_t)jbaseL, (int)owner) | ((uint64_t)__shfl((uint32_t)(jbaseL >> 32), (int)owner) << 32);
+        const uint64_t jr = (uint64_t)__shfl((uint32_t)jbaseR, (int)owner) | ((uint64_t)__shfl((uint32_t)(jbaseR >> 32), (int)owner) << 32);
+        const uint64_t ml = (uint64_t)__shfl((uint32_t)mbaseL, (int)owner) | ((uint64_t)__shfl((uint32_t)(mbaseL >> 32), (int)owner) << 32);
+        const uint64_t mr = (uint64_t)__shfl((uint32_t)mbaseR, (int)owner) | ((uint64_t)__shfl((uint32_t)(mbaseR >> 32), (int)owner) << 32);
+        cL[q] = act[q] ? (uint32_t)S.meta[ml + (uint64_t)b * n] : 0u;
+        cR[q] = act[q] ? (uint32_t)S.meta[mr + (uint64_t)b * n] : 0u;
+        Lj[q] = S.jumps + jl + (uint64_t)b * Cn;
+        Rj[q] = S.jumps + jr + (uint64_t)b * Cn;
+      }
+      double tl0[NP], tr0[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        tl0[q] = (cL[q] & EPV_NJ_MASK) ? Lj[q][0] : EPV_INF;
+        tr0[q] = (cR[q] & EPV_NJ_MASK) ? Rj[q][0] : EPV_INF;
+      }
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        if (!act[q]) continue;
+        const uint32_t owner = (uint32_t)pr[q] & 63u, node = ((uint32_t)pr[q] >> 6) & 63u, hcur = (uint32_t)(pr[q] >> 32);
+        const uint32_t nL = cL[q] & EPV_NJ_MASK, nR = cR[q] & EPV_NJ_MASK, K = nL + nR + 1u;
+        uint32_t trip0 = 4u * (cL[q] >> EPV_INIT_SHIFT) + (cR[q] >> EPV_INIT_SHIFT), i = 0, j = 0;
         double seg_start = 0.0;
-        double tl = nL ? Lj[0] : EPV_INF, tr = nR ? Rj[0] : EPV_INF;
+        double tl = tl0[q], tr = tr0[q];
         for (uint32_t k = 0; k < K; ++k) {
           const bool last_seg = (k + 1u == K);
           const bool take_left = tl < tr;
@@ -168,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
           rec[LEN_AT] = seg_end - seg_start;
           rec[INFO_AT] = epv_u2d((uint64_t)trip0 | ((uint64_t)owner << 3) | ((uint64_t)node << 9) | ((uint64_t)k << 21));
           if (!last_seg) {
-            if (take_left) { trip0 ^= 4u; ++i; tl = i < nL ? Lj[(uint64_t)i * n] : EPV_INF; }
-            else { trip0 ^= 1u; ++j; tr = j < nR ? Rj[(uint64_t)j * n] : EPV_INF; }
+            if (take_left) { trip0 ^= 4u; ++i; tl = i < nL ? Lj[q][(uint64_t)i * n] : EPV_INF; }
+            else { trip0 ^= 1u; ++j; tr = j < nR ? Rj[q][(uint64_t)j * n] : EPV_INF; }
             seg_start = seg_end;
           }
         }
@@ -177,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    P2_MARK(2);
     // ---- 3. evaluate them densely, one segment per lane: matrices, no-jump bounds, the segment's
     //         Philox block (none of which depends on the recursion state)
     for (uint32_t i = (uint32_t)lane; i < totH; i += 64u) {
@@ -194,14 +230,28 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
       rec[7] = blk.d1;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();     // (the pair list's space becomes the stack)
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- 4. pruning, reverse pre-order (SingleSiteSampler.cpp:116-157)
+    P2_MARK(3);
+    // ---- 4. pruning, reverse pre-order (SingleSiteSampler.cpp:116-157).  The matrix entries of a heavy
+    //         branch are fetched four segments at a time, at the top of the node's iteration: one
+    //         round trip per branch (K <= 4) instead of one per segment
     if (run) {
-      uint32_t hcur = hbase + heavy;
+      uint32_t hcur = hbase + heavy;      // one past the next record (records are consumed last to first)
       for (uint32_t node = S.N - 1u; node >= 1u; --node) {
         const uint32_t nw = s_node[node];
         const uint32_t e = s_ent[node * 64u + lane];
+        uint32_t K = 0u, m = 0u;
+        double m00 = 0.0, m01 = 0.0, m10 = 0.0, m11 = 0.0, m20 = 0.0, m21 = 0.0, m30 = 0.0, m31 = 0.0;
+        if (e & EPV_P3_HEAVY) {
+          K = segments_of(e, node);
+          m = K < 4u ? K : 4u;
+          const double *r = list + (size_t)(hcur - 1u) * HREC;
+          m00 = r[0]; m01 = r[1];
+          m10 = r[-(int)HREC]; m11 = r[1 - (int)HREC];      // (K >= 2: the record exists)
+          if (m > 2u) { m20 = r[-2 * (int)HREC]; m21 = r[1 - 2 * (int)HREC]; }
+          if (m > 3u) { m30 = r[-3 * (int)HREC]; m31 = r[1 - 3 * (int)HREC]; }
+        }
         double n0, n1;
         if (EPV_P3_LEAF(nw)) {
           const uint32_t leaf_state = ((e >> 2) ^ (e >> 3)) & 1u;
@@ -221,16 +271,32 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
           const double c = P10 * n0 + P11 * n1;
           n0 = a; n1 = c;
         } else {
-          const uint32_t K = segments_of(e, node);
-          hcur -= K;
-          for (uint32_t kk = K; kk-- > 0u;) {
-            double *hr = list + (size_t)(hcur + kk) * HREC;
-            const double P00 = hr[0], P11 = hr[1];
-            const double P01 = 1.0 - P00, P10 = 1.0 - P11;
-            const double a = P00 * n0 + P01 * n1;
-            const double c = P10 * n0 + P11 * n1;
-            hr[0] = a; hr[1] = c;       // p[kk] takes the place of the matrix
-            n0 = a; n1 = c;
+          uint32_t left = K;
+          for (;;) {
+            double *hr = list + (size_t)(hcur - 1u) * HREC;
+            // p[kk] = M[kk] p[kk + 1]; it takes the place of the matrix in the record
+#define EPV_P3_STEP(P00_, P11_, BACK)                                        \
+            {                                                                 \
+              const double P01 = 1.0 - (P00_), P10 = 1.0 - (P11_);            \
+              const double a = (P00_) * n0 + P01 * n1;                         \
+              const double c = P10 * n0 + (P11_) * n1;                         \
+              hr[-(int)((BACK) * HREC)] = a; hr[1 - (int)((BACK) * HREC)] = c; \
+              n0 = a; n1 = c;                                                  \
+            }
+            EPV_P3_STEP(m00, m01, 0u)
+            if (m > 1u) EPV_P3_STEP(m10, m11, 1u)
+            if (m > 2u) EPV_P3_STEP(m20, m21, 2u)
+            if (m > 3u) EPV_P3_STEP(m30, m31, 3u)
+#undef EPV_P3_STEP
+            hcur -= m;
+            left -= m;
+            if (left == 0u) break;
+            m = left < 4u ? left : 4u;
+            const double *r = list + (size_t)(hcur - 1u) * HREC;
+            m00 = r[0]; m01 = r[1];
+            if (m > 1u) { m10 = r[-(int)HREC]; m11 = r[1 - (int)HREC]; }
+            if (m > 2u) { m20 = r[-2 * (int)HREC]; m21 = r[1 - 2 * (int)HREC]; }
+            if (m > 3u) { m30 = r[-3 * (int)HREC]; m31 = r[1 - 3 * (int)HREC]; }
           }
         }
         // p.front of this branch into its parent's product (a child of the root has no use for it:
@@ -243,28 +309,95 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- 5. downward sampling of the segment END STATES (:180-255); the jump times are drawn by
-    //         epv_mh_jumps_kernel for the dirty branches only
+    P2_MARK(4);
+    // ---- 5. the heavy branches' end states for BOTH start states, one pair per lane.  The uniforms
+    //         of a segment are fixed, so the chain of end states along a branch is a function of the
+    //         start state alone: evaluating it for 0 and for 1 here, densely, leaves the sequential
+    //         walk over the tree below with a table lookup where the first kernel iterated
+    //         max_lanes(K) times over a division with a tenth of the lanes busy.  The words of
+    //         sampled states for both start states wait in the first record's PT slots, which this
+    //         pass has used by then.  (More than 64 segments: the walk's own loop, EPV_P3_SLOW.)
+    for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
+      const uint32_t pidx = p0 + (uint32_t)lane;
+      if (pidx < totP) {
+        const unsigned long long pr = plist[pidx];
+        const uint32_t owner = (uint32_t)pr & 63u, node = ((uint32_t)pr >> 6) & 63u, K = ((uint32_t)pr >> 12) & 0xfffffu;
+        const uint32_t hrec0 = (uint32_t)(pr >> 32);
+        if (K <= 64u) {
+          const uint32_t nw = s_node[node];
+          const uint32_t e = s_ent[node * 64u + owner];
+          double q0, q1;
+          if (EPV_P3_LEAF(nw)) {
+            const uint32_t leaf_state = ((e >> 2) ^ (e >> 3)) & 1u;
+            q0 = leaf_state ? 0.0 : 1.0;
+            q1 = leaf_state ? 1.0 : 0.0;
+          } else {
+            const double *qr = qrows + (size_t)EPV_P3_QROW(nw) * 128u + (size_t)owner * 2u;
+            q0 = qr[0]; q1 = qr[1];
+          }
+          double *hr = list + (size_t)hrec0 * HREC;
+          uint32_t prevA = 0u, prevB = 1u;            // chains from start state 0 and from start state 1
+          bool cleanA = true, cleanB = true;
+          unsigned long long wA = 0ull, wB = 0ull;
+          double pk0 = hr[0], pk1 = hr[1];
+          for (uint32_t k = 0; k < K; ++k) {
+            const bool last_seg = (k + 1u == K);
+            const double nxt0 = last_seg ? q0 : hr[HREC], nxt1 = last_seg ? q1 : hr[HREC + 1u];
+            const double PT00 = hr[2], PT10 = hr[3], nb0 = hr[4], nb1 = hr[5], u_end = hr[6], u_first = hr[7];
+            const double p0A = (prevA ? PT10 : PT00) * nxt0 / (prevA ? pk1 : pk0);
+            const double p0B = (prevB ? PT10 : PT00) * nxt0 / (prevB ? pk1 : pk0);
+            const uint32_t sA = (u_end > p0A) ? 1u : 0u, sB = (u_end > p0B) ? 1u : 0u;
+            cleanA = cleanA && (sA == prevA) && (1.0 - u_first < (prevA ? nb1 : nb0));
+            cleanB = cleanB && (sB == prevB) && (1.0 - u_first < (prevB ? nb1 : nb0));
+            wA |= (unsigned long long)sA << k;
+            wB |= (unsigned long long)sB << k;
+            prevA = sA; prevB = sB;
+            pk0 = nxt0; pk1 = nxt1;
+            hr += HREC;
+          }
+          double *h0 = list + (size_t)hrec0 * HREC;
+          h0[2] = epv_u2d(wA);
+          h0[3] = epv_u2d(wB);
+          s_ent[node * 64u + owner] = (uint16_t)((e & 0x0fffu) | (prevA << 12) | ((cleanA ? 1u : 0u) << 13) |
+                                                 (prevB << 14) | ((cleanB ? 1u : 0u) << 15));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    P2_MARK(5);
+    // ---- 6. downward sampling of the segment END STATES (:180-255); the jump times are drawn by
+    //         epv_mh_jumps_kernel for the dirty branches only.  q of the next internal node is
+    //         requested one node ahead.
     unsigned long long dirty = 0ull, multi = 0ull, deep = 0ull;
     bool ident = true;
     const uint32_t root_state = run ? ((uint32_t)s_ent[64u + lane] >> 2) & 1u : 0u;
     if (run) {
       uint32_t hcur = hbase;
+      double qn0 = 0.0, qn1 = 0.0;
+      {
+        const uint32_t nw1 = s_node[1];
+        if (!EPV_P3_LEAF(nw1)) { const double *qr = qrows + (size_t)EPV_P3_QROW(nw1) * 128u + (size_t)lane * 2u; qn0 = qr[0]; qn1 = qr[1]; }
+      }
       for (uint32_t node = 1u; node < S.N; ++node) {
         const uint32_t b = node - 1u;
         const uint32_t nw = s_node[node];
         const uint32_t e = s_ent[node * 64u + lane];
         const uint32_t par = EPV_P3_PARENT(nw);
         const uint32_t start_state = (par == 0u) ? root_state : ((uint32_t)s_ent[par * 64u + lane] >> 6) & 1u;
-        double q0, q1;
+        double q0 = qn0, q1 = qn1;
         if (EPV_P3_LEAF(nw)) {
           const uint32_t leaf_state = ((e >> 2) ^ (e >> 3)) & 1u;
           q0 = leaf_state ? 0.0 : 1.0;
           q1 = leaf_state ? 1.0 : 0.0;
-        } else {
-          const double *qr = qrows + (size_t)EPV_P3_QROW(nw) * 128u + (size_t)lane * 2u;
-          q0 = qr[0]; q1 = qr[1];
+        }
+        if (node + 1u < S.N) {
+          const uint32_t nwn = s_node[node + 1u];
+          if (!EPV_P3_LEAF(nwn)) { const double *qr = qrows + (size_t)EPV_P3_QROW(nwn) * 128u + (size_t)lane * 2u; qn0 = qr[0]; qn1 = qr[1]; }
         }
         uint32_t prev = start_state, K = 1u;
         bool clean;
@@ -282,6 +415,11 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
           clean = (sampled == prev) && (1.0 - blk.d1 < nb);
           if (!clean) S.prop_states[((uint64_t)b * S.phase_cap + tid) * S.W] = (unsigned long long)sampled;
           prev = sampled;
+        } else if (!(e & EPV_P3_SLOW)) {
+          K = segments_of(e, node);
+          hcur += K;
+          clean = (e >> (start_state ? 15u : 13u)) & 1u;
+          prev = (e >> (start_state ? 14u : 12u)) & 1u;
         } else {
           K = segments_of(e, node);
           clean = true;
@@ -306,7 +444,9 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
           hcur += K;
           if ((K & 63u) && !clean) states[(K - 1u) >> 6] = word;   // only a dirty branch is read back
         }
-        s_ent[node * 64u + lane] = (uint16_t)(e | (prev << 6));   // proposal end state for the children
+        // proposal end state for the children (bit 6), "dirty" for the pair pass below (bit 7 of a heavy branch)
+        s_ent[node * 64u + lane] = (uint16_t)((e & ~EPV_P3_SLOW) | (prev << 6) |
+                                              ((e & EPV_P3_HEAVY) && !(e & EPV_P3_SLOW) && !clean ? EPV_P3_SLOW : 0u));
         // same as the current path?  (no jumps on either, same start state)
         ident = ident && clean && !(e & 16u) && ((e >> 2) & 1u) == start_state;
         if (!clean) {
@@ -316,9 +456,27 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- 7. the words of sampled states of the dirty heavy branches, one pair per lane again
+    for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
+      const uint32_t pidx = p0 + (uint32_t)lane;
+      if (pidx < totP) {
+        const unsigned long long pr = plist[pidx];
+        const uint32_t owner = (uint32_t)pr & 63u, node = ((uint32_t)pr >> 6) & 63u;
+        const uint32_t e = s_ent[node * 64u + owner];
+        if (e & EPV_P3_SLOW) {           // (bit 7 now: heavy, at most 64 segments, dirty)
+          const uint32_t par = EPV_P3_PARENT(s_node[node]);
+          const uint32_t st = (par == 0u) ? ((uint32_t)s_ent[64u + owner] >> 2) & 1u : ((uint32_t)s_ent[par * 64u + owner] >> 6) & 1u;
+          const double *h0 = list + (size_t)(uint32_t)(pr >> 32) * HREC;
+          S.prop_states[((uint64_t)(node - 1u) * S.phase_cap + (tid - (uint32_t)lane + owner)) * S.W] = epv_d2u(h0[2u + st]);
+        }
+      }
+    }
+    P2_MARK(6);
     epv_flush_tasks(S, counters, dirty, multi, deep, B - 1u, site, lane, my_shard);
 
-    // ---- 6. hand-over.  A proposal equal to the current path is accepted with probability one and
+    // ---- 8. hand-over.  A proposal equal to the current path is accepted with probability one and
     //         changes neither the paths nor the cached likelihoods: count it and be done.  Everything
     //         else: start states of the proposal's branches into the other buffer, and the site onto
     //         the accept list of this wave's shard.
@@ -347,9 +505,17 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
         atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_ACCEPT, my_shard)], (unsigned long long)__popcll(am));
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();     // the stack's space goes back to the next round's pair list
+    __builtin_amdgcn_wave_barrier();     // (a later round reuses the pair list and the records)
     pending = pending && !run;
+    P2_MARK(7);
   }
+#ifdef EPV_P2_PROFILE
+  if (epv_lane() == 0) {
+    unsigned long long *row = epv_p2_prof + 16u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % EPV_P2_PROF_ROWS);
+    for (int q = 0; q < 15; ++q) row[q] += t_acc_[q];
+    row[15] += 1ull;
+  }
+#endif
 }
 
 #endif
