@@ -74,9 +74,9 @@ struct epv_ctx {
   // third proposal kernel (epv_propose3.h): large trees, where the record pool does not fit LDS
   int use_p3 = -1;               // -1 = whenever the plan allows it, EPV_PROPOSE_V3=0/1 forces
   bool p3 = false;               // decided by plan_p3 for the uploaded tree and paths
-  uint32_t p3_list_cap = 0, p3_qrows = 0, p3_levels = 0;
+  uint32_t p3_list_cap = 0, p3_qrows = 0, p3_nup = 0, p3_depth = 0;
   size_t p3_lds = 0;
-  uint32_t *d_nodetab = nullptr; // [N] parent | level | q row | leaf | last child (EPV_P3_*)
+  uint32_t *d_nodetab = nullptr; // node words and level lists of epv_mh_propose3_kernel (EPV_P3_*)
   uint32_t phase_parity = 0;     // accept lists are double-buffered by phase parity
   int use_seg = -1;              // segment-parallel jump kernels (epv_jumps2.h): -1 = by workload
                                  // (long branches, kbar >= 0.25), EPV_SEG_JUMPS=0/1 forces
@@ -285,27 +285,48 @@ int plan_p3(epv_ctx *c) {
   const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
   if (c->use_p3 == 0 || !c->use_p2 || N > 64u || N < 2u) return EPV_OK;
   if (c->use_p3 < 0 && !c->p2_gpool) return EPV_OK;     // the LDS pool is the better place while it fits
-  // per node: parent, depth, children; q rows for the internal nodes below the root
-  std::vector<uint32_t> depth(N, 0u), kids(N, 0u), tab(N, 0u);
-  uint32_t qrows = 0, levels = 0;
+  // per node: parent, children, depth; q rows for the internal nodes below the root
+  std::vector<uint32_t> depth(N, 0u), c1(N, 0u), c2(N, 0u), kids(N, 0u), qrow(N, 0u);
+  uint32_t qrows = 0, max_depth = 0;
   for (uint32_t node = 1; node < N; ++node) {
-    depth[node] = depth[c->parent[node]] + 1u;
-    ++kids[c->parent[node]];
-  }
-  for (uint32_t node = 1; node < N; ++node) {
-    const bool leaf = c->subtree[node] == 1u;
-    if (kids[node] > 2u) return EPV_OK;     // (a product of three partials does not commute bit for bit)
     const uint32_t par = c->parent[node];
-    const bool last_child = node + c->subtree[node] == par + c->subtree[par];
-    uint32_t w = par | ((depth[node] - 1u) << 6) | ((leaf ? 1u : 0u) << 18) | ((last_child ? 1u : 0u) << 19);
-    if (!leaf) {
-      w |= qrows << 12;
-      ++qrows;
-      levels = std::max(levels, depth[node]);
-    }
-    tab[node] = w;
+    if (par >= node) return EPV_OK;                      // (pre-order is what epv_set_tree checks; be safe)
+    depth[node] = depth[par] + 1u;
+    max_depth = std::max(max_depth, depth[node]);
+    if (kids[par] == 0u) c1[par] = node; else if (kids[par] == 1u) c2[par] = node;
+    ++kids[par];
   }
-  if (levels > 24u) return EPV_OK;          // a 1 KB stack level per depth: keep >= 2 waves per SIMD
+  for (uint32_t node = 1; node < N; ++node) {
+    if (kids[node] > 2u) return EPV_OK;                  // two child fields per node word
+    if (c->subtree[node] != 1u) qrow[node] = qrows++;
+  }
+  if (max_depth > 62u) return EPV_OK;
+  // tables: node words [N] | internal nodes deepest first [n_up] | their level starts [D + 2] |
+  //         all nodes but the root by depth [N - 1] | their level starts [D + 2]
+  std::vector<uint32_t> tab;
+  for (uint32_t node = 0; node < N; ++node)
+    tab.push_back(c->parent[node] | (c1[node] << 6) | (c2[node] << 12) | (qrow[node] << 18) |
+                  ((c->subtree[node] == 1u ? 1u : 0u) << 24) | (depth[node] << 25));
+  std::vector<uint32_t> up, upstart(max_depth + 2u, 0u), dn, dnstart(max_depth + 2u, 0u);
+  for (uint32_t d = max_depth + 1u; d-- > 0u;) {        // upstart[d + 1] .. upstart[d] = internal nodes of depth d
+    if (d <= max_depth && d >= 1u)
+      for (uint32_t node = 1; node < N; ++node)
+        if (depth[node] == d && c->subtree[node] != 1u) up.push_back(node);
+    upstart[d] = (uint32_t)up.size();
+  }
+  upstart[max_depth + 1u] = 0u;
+  for (uint32_t d = 0; d <= max_depth; ++d) {           // dnstart[d] .. dnstart[d + 1] = nodes of depth d
+    dnstart[d] = (uint32_t)dn.size();
+    if (d >= 1u)
+      for (uint32_t node = 1; node < N; ++node)
+        if (depth[node] == d) dn.push_back(node);
+  }
+  dnstart[max_depth + 1u] = (uint32_t)dn.size();
+  const uint32_t n_up = (uint32_t)up.size();
+  tab.insert(tab.end(), up.begin(), up.end());
+  tab.insert(tab.end(), upstart.begin(), upstart.end());
+  tab.insert(tab.end(), dn.begin(), dn.end());
+  tab.insert(tab.end(), dnstart.begin(), dnstart.end());
   const double lam = 2.0 * c->kbar;
   const double heavy_per_branch = (1.0 + lam) - std::exp(-lam);
   const uint64_t worst_heavy = (uint64_t)B * (2u * C + 1u);
@@ -323,15 +344,15 @@ int plan_p3(epv_ctx *c) {
     HIP_TRY(c, hipMalloc(&c->d_gpool2, need * sizeof(double)));
     c->gpool2_cap = need;
   }
-  if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 64u * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemcpy(c->d_nodetab, tab.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice));
-  const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * EPV_SEGTAB_DBL * 8u + (size_t)((N + 1u) / 2u) * 8u;
-  const size_t per_wave = ((size_t)N * 64u * 2u + 15u) / 16u * 16u + (size_t)levels * 128u * 8u;
+  if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 512u * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemcpy(c->d_nodetab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * EPV_SEGTAB_DBL * 8u + (tab.size() + 1u) / 2u * 8u;
+  const size_t per_wave = ((size_t)EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u) * 8u;     // pair results: p.front, result bits
   c->p3_lds = shared + 4u * per_wave;
-  if (c->p3_lds > 160u * 1024u) return EPV_OK;
   c->p3_list_cap = (uint32_t)list_cap;
   c->p3_qrows = qrows;
-  c->p3_levels = levels;
+  c->p3_nup = n_up;
+  c->p3_depth = max_depth;
   c->p3 = true;
   return EPV_OK;
 }
@@ -580,7 +601,7 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     const unsigned pb = (unsigned)((threads + 255u) / 256u);
     hipLaunchKernelGGL(epv_mh_propose3_kernel<false>, dim3(pb), dim3(256), c->p3_lds, c->stream, c->S, (uint32_t)colour,
                        (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->p3_list_cap,
-                       c->p3_qrows, c->p3_levels, c->phase_parity & 1u, c->d_counters, c->d_gpool2, c->d_segtab,
+                       c->p3_qrows, c->p3_nup, c->p3_depth, c->phase_parity & 1u, c->d_counters, c->d_gpool2, c->d_segtab,
                        c->d_nodetab);
     ++c->phase_parity;
   } else if (p2) {

@@ -7,71 +7,84 @@
 // (site, branch) pairs onto the bucketed lists of epv_mh_jumps_kernel, sites whose proposal differs
 // from their path onto the accept list -- built around what the counters said about the 16-leaf
 // tree (profiles/r03f_pmc_*_bal16.csv): the first kernel there is bound by memory latency and
-// fabric bandwidth, not by issue.  Its waves walk 30 branches with two or three dependent global
-// round trips each (meta words, jump planes of whichever lane is heavy at that node, the records of
-// the children), and the Felsenstein records of 64 sites x 30 branches (2 KB per site) do not fit
-// LDS, so they stream through a slab of global memory: 2 GB written and read back per phase.
+// fabric bandwidth, not by issue.  Its waves walk 30 branches, each step with two or three
+// dependent global round trips (meta words, jump planes of whichever lane is heavy at that node,
+// the records of the children), and the Felsenstein records of 64 sites x 30 branches (2 KB per
+// site) do not fit LDS, so they stream through a slab of global memory: 2 GB written and read back
+// per phase.
 //
-// Here a wave keeps in LDS only a 16-bit word per (node, lane) -- neighbour start states, leaf
-// state, "has a neighbour jump", min(K - 1, 255), later the proposal's end state -- and a stack of
-// partial products, one level per tree depth.  What goes to global memory per wave:
-//   * q of the INTERNAL nodes (14 of 30 on the 16-leaf tree), one coalesced 1 KB row each, written
-//     once by pruning and read once by the downward pass.  p.front of a branch is never stored: its
-//     parent multiplies it into the stack level of its depth the moment it exists (a node with two
-//     children: q = p_first * p_second either way round, the product of two doubles commutes), and
-//     the downward pass recomputes it from q and the matrix table (one segment) or finds it in the
-//     heavy record (several segments);
-//   * the records of the heavy segments (branches with a neighbour jump: ~10 % of the pairs), 64 B
-//     each, listed by one lane per (site, branch) pair and evaluated one SEGMENT per lane as in
-//     epv_mh_propose2_kernel -- all merges of a wave in one chain of round trips instead of one
-//     chain per node.  A record's matrix entries give way to the partials p[k] once pruning has used them.
-// No node table, no record pool: ~8 KB of LDS per wave instead of 19.5 (second kernel) and about a
-// fifth of the first kernel's record traffic.
+// Here nothing about a (node, lane) pair lives in memory at all unless the branch is heavy:
+//   * what the recursions need to know about a branch -- the neighbours' start states, this path's
+//     start state / jump parity / "has jumps", "a neighbour jumps on it" (heavy) -- are six 64-bit
+//     masks per lane, one bit per node (N <= 64), filled from one batch of meta-word loads;
+//   * the tree is walked LEVEL BY LEVEL, not node by node: the nodes of a level are independent, so
+//     their global loads are issued together and a wave waits once per level (4 on the 16-leaf tree)
+//     instead of once or twice per node (30);
+//   * q of an internal node = the product of its children's p.front, written once as a coalesced
+//     1 KB row per wave (14 rows on the 16-leaf tree) and read back by the level above and by the
+//     downward pass; p.front itself is recomputed from q and the matrix table where needed;
+//   * heavy branches (~10 % of the pairs) get a lane each: the pairs are listed, their segments
+//     merged (Segment.cpp:35-79) and evaluated densely as in epv_mh_propose2_kernel; then, level by
+//     level behind the nodes' pass, a pair lane runs the branch's pruning chain from registers and --
+//     the uniforms of a segment being fixed -- the chain of end states for BOTH start states, leaving
+//     p.front (16 B) and four result bits in LDS for the lanes that own the sites.  The sequential
+//     parts never iterate over segments.
+// LDS per wave: 4.3 KB (pair results) instead of 19.5 (second kernel); global traffic per wave: the
+// 14 q rows and the heavy records.
 //
-// Preconditions (plan_p3, epv_abi.hip): N <= 64 (node masks are one word), every node but the
-// root has at most two children, the stack fits its LDS budget.
+// Preconditions (plan_p3, epv_abi.hip): N <= 64, every node but the root has at most two children.
 
-#define EPV_P3_PCAP 512u   /* heavy (lane, node) pairs a wave lists per round (at least 64: one lane's worst case) */
+#define EPV_P3_PCAP 256u   /* heavy (lane, node) pairs a wave lists per round (at least 64: one lane's worst case) */
 
-// s_node[node]: parent | (depth - 1) << 6 | q row << 12 | leaf << 18 | last child of its parent << 19
+// s_tree[node]: parent | first child << 6 | second child << 12 | q row << 18 | leaf << 24 | depth << 25
 #define EPV_P3_PARENT(w) ((w) & 63u)
-#define EPV_P3_LEVEL(w) (((w) >> 6) & 63u)
-#define EPV_P3_QROW(w) (((w) >> 12) & 63u)
-#define EPV_P3_LEAF(w) (((w) >> 18) & 1u)
-#define EPV_P3_LASTCHILD(w) (((w) >> 19) & 1u)
+#define EPV_P3_CHILD1(w) (((w) >> 6) & 63u)
+#define EPV_P3_CHILD2(w) (((w) >> 12) & 63u)
+#define EPV_P3_QROW(w) (((w) >> 18) & 63u)
+#define EPV_P3_LEAF(w) (((w) >> 24) & 1u)
+#define EPV_P3_DEPTH(w) (((w) >> 25) & 63u)
+// pair word: lane | node << 6 | segments << 12 | first record << 32 | leaf state << 62
+// s_pb[pair]: end state for start state 0 | clean << 1 | end state for start 1 << 2 | clean << 3 |
+//             (K == 2 or K >= 4) << 4 | (K >= 3) << 5   (the task buckets of epv_flush_tasks)
 
-// s_ent[node * 64 + lane]: bit 0 right neighbour's start state, 1 left neighbour's, 2 this path's,
-// 3 parity of this path's jump count, 4 this path has jumps, 5 heavy (a neighbour jumps on the
-// branch), 6 the proposal's end state (downward pass), 7 more than 64 segments (the sequential
-// loop of the downward pass), bits 8..11 min(K - 1, 15), bits 12..15 of a heavy branch: end state
-// and "clean" for start state 0, the same for start state 1 (the pair pass behind pruning)
-#define EPV_P3_HEAVY 32u
-#define EPV_P3_SLOW 128u
-
+#ifndef EPV_P3_KREG
+#define EPV_P3_KREG 3u   /* segments of a heavy branch the pair pass keeps in registers (8 doubles each); longer ones go through memory */
+#endif
+#ifndef EPV_P3_NP
+#define EPV_P3_NP 2      /* chunks of 64 pairs the merge pass interleaves */
+#endif
+#ifndef EPV_P3_MINBLOCKS
+#define EPV_P3_MINBLOCKS 2   /* blocks of four waves per CU the register allocation aims for */
+#endif
 template <bool DUMMY>
-__global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
+__global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first,
-    uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t list_cap, uint32_t n_qrows, uint32_t levels,
-    uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab, const uint32_t *nodetab) {
+    uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t list_cap, uint32_t n_qrows, uint32_t n_up,
+    uint32_t depth, uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab,
+    const uint32_t *nodetab) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   constexpr uint32_t HREC = EPV_HREC_SHORT, LEN_AT = HREC - 2u, INFO_AT = HREC - 1u;
 #ifdef EPV_P2_PROFILE
   unsigned long long t_acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_prev_ = __builtin_readcyclecounter();
 #endif
-  const uint32_t const_dbl = (20u + S.N + 1u) & ~1u;
-  const uint32_t tab_dbl = S.B * 4u * EPV_SEGTAB_DBL;
-  const uint32_t node_dbl = (S.N + 1u) / 2u;
-  const uint32_t ent_dbl = (S.N * 64u * (uint32_t)sizeof(uint16_t) + 15u) / 16u * 2u;
-  const uint32_t stk_dbl = levels * 128u;     // the stack of partial products (pruning)
+  const uint32_t N = S.N, B = S.B;
+  const uint32_t const_dbl = (20u + N + 1u) & ~1u;
+  const uint32_t tab_dbl = B * 4u * EPV_SEGTAB_DBL;
+  // tree tables: node words [N], internal nodes deepest level first [n_up] with level starts
+  // [depth + 2] (level d from s_upstart[d + 1] to s_upstart[d]), all nodes but the root by depth
+  // [N - 1] with level starts [depth + 2] (level d from s_dnstart[d] to s_dnstart[d + 1])
+  const uint32_t tree_words = N + n_up + (depth + 2u) + (N - 1u) + (depth + 2u);
+  const uint32_t tree_dbl = (tree_words + 1u) / 2u;
+  const uint32_t wave_dbl = EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u;
   const uint32_t wave_id = threadIdx.x >> 6;
-  const uint32_t wave_dbl = ent_dbl + stk_dbl;
   double *s_const = s_mem;
   double *s_tab = s_mem + const_dbl;
-  uint32_t *s_node = reinterpret_cast<uint32_t *>(s_mem + const_dbl + tab_dbl);
-  double *s_wave = s_mem + const_dbl + tab_dbl + node_dbl + (size_t)wave_id * wave_dbl;
-  uint16_t *s_ent = reinterpret_cast<uint16_t *>(s_wave);
-  double *s_stk = s_wave + ent_dbl;
+  uint32_t *s_tree = reinterpret_cast<uint32_t *>(s_mem + const_dbl + tab_dbl);
+  const uint32_t *s_up = s_tree + N, *s_upstart = s_up + n_up;
+  const uint32_t *s_dn = s_upstart + (depth + 2u), *s_dnstart = s_dn + (N - 1u);
+  double *s_pf = s_mem + const_dbl + tab_dbl + tree_dbl + (size_t)wave_id * wave_dbl;
+  uint8_t *s_pb = reinterpret_cast<uint8_t *>(s_pf + EPV_P3_PCAP * 2u);
   const int lane = epv_lane();
   const uint32_t my_shard = (blockIdx.x * (blockDim.x >> 6) + wave_id) & (EPV_SHARDS - 1u);
   // per-wave slab: the pair list, q rows of 64 interleaved records, the flat heavy list
@@ -86,14 +99,13 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
   const uint64_t site = s0 + 3u * tid;
   const bool valid = site <= last;
   const uint64_t n = S.n;
-  const uint32_t B = S.B;
   const uint32_t gsite = (uint32_t)(S.g0 + site);
   const uint32_t gsite_lane0 = gsite - 3u * (uint32_t)lane;
 
   uint32_t selL = 0, selM = 0, selR = 0;
   if (valid) { selL = S.sel[site - 1]; selM = S.sel[site]; selR = S.sel[site + 1]; }
   for (uint32_t i = threadIdx.x; i < tab_dbl; i += blockDim.x) s_tab[i] = segtab[i];
-  for (uint32_t i = threadIdx.x; i < S.N; i += blockDim.x) s_node[i] = nodetab[i];
+  for (uint32_t i = threadIdx.x; i < tree_words; i += blockDim.x) s_tree[i] = nodetab[i];
   stage_constants(S, s_const);
   const double *s_rates = s_const;
   const double *s_blen = s_const + 20;
@@ -102,30 +114,27 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
   const uint64_t mbaseL = (selL ? Bn : 0ull) + (site - 1), mbaseR = (selR ? Bn : 0ull) + (site + 1);
   const uint64_t mbaseM = (selM ? Bn : 0ull) + site;
   const uint64_t jbaseL = (selL ? Bn * S.C : 0ull) + (site - 1), jbaseR = (selR ? Bn * S.C : 0ull) + (site + 1);
-  // ---- 0. the meta words of the three columns, in batches of independent loads, condensed to one
-  //         16-bit word per (node, lane)
+  // ---- 0. the meta words of the three columns, in batches of independent loads, condensed to six
+  //         masks (bit `node` = the branch above the node)
+  unsigned long long mR = 0ull, mL = 0ull, mM = 0ull, mMp = 0ull, mMj = 0ull, mH = 0ull;
   uint32_t heavy = 0, n_pairs = 0;
   if (valid) {
 #pragma unroll 6
     for (uint32_t b = 0; b < B; ++b) {
-      const uint32_t mL = S.meta[mbaseL + (uint64_t)b * n];
-      const uint32_t mR = S.meta[mbaseR + (uint64_t)b * n];
-      const uint32_t mM = S.meta[mbaseM + (uint64_t)b * n];
-      const uint32_t K = (mL & EPV_NJ_MASK) + (mR & EPV_NJ_MASK) + 1u;
-      const uint32_t e = (mR >> EPV_INIT_SHIFT) | ((mL >> EPV_INIT_SHIFT) << 1) | ((mM >> EPV_INIT_SHIFT) << 2) |
-                         ((mM & 1u) << 3) | ((mM & EPV_NJ_MASK) ? 16u : 0u) | (K >= 2u ? EPV_P3_HEAVY : 0u) |
-                         (K > 64u ? EPV_P3_SLOW : 0u) | ((K - 1u < 15u ? K - 1u : 15u) << 8);
-      s_ent[(b + 1u) * 64u + lane] = (uint16_t)e;
-      if (K >= 2u) { heavy += K; ++n_pairs; }
+      const uint32_t wL = S.meta[mbaseL + (uint64_t)b * n];
+      const uint32_t wR = S.meta[mbaseR + (uint64_t)b * n];
+      const uint32_t wM = S.meta[mbaseM + (uint64_t)b * n];
+      const uint32_t K = (wL & EPV_NJ_MASK) + (wR & EPV_NJ_MASK) + 1u;
+      const uint32_t node = b + 1u;
+      mR |= (unsigned long long)(wR >> EPV_INIT_SHIFT) << node;
+      mL |= (unsigned long long)(wL >> EPV_INIT_SHIFT) << node;
+      mM |= (unsigned long long)(wM >> EPV_INIT_SHIFT) << node;
+      mMp |= (unsigned long long)(wM & 1u) << node;
+      mMj |= (unsigned long long)((wM & EPV_NJ_MASK) ? 1u : 0u) << node;
+      if (K >= 2u) { mH |= 1ull << node; heavy += K; ++n_pairs; }
     }
   }
-  // segments of the branch above `node` (the word holds it up to 15; beyond, from the meta words)
-  auto segments_of = [&](uint32_t e, uint32_t node) __attribute__((always_inline)) -> uint32_t {
-    const uint32_t k4 = (e >> 8) & 15u;
-    if (k4 < 15u) return k4 + 1u;
-    return (uint32_t)(S.meta[mbaseL + (uint64_t)(node - 1u) * n] & EPV_NJ_MASK) +
-           (uint32_t)(S.meta[mbaseR + (uint64_t)(node - 1u) * n] & EPV_NJ_MASK) + 1u;
-  };
+  const uint32_t root_state = (uint32_t)(mM >> 1) & 1u;     // init of branch 0's path (PATH(1, site)->init)
 
   P2_MARK(0);
   bool pending = valid;
@@ -137,28 +146,47 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
     const unsigned long long rmask = __ballot(run);
     const int hi_lane = rmask ? 63 - __clzll((long long)rmask) : 0;
     const uint32_t totH = rmask ? epv_bcast(inclH, hi_lane) : 0u, totP = rmask ? epv_bcast(inclP, hi_lane) : 0u;
-    const uint32_t hbase = inclH - wantH;
+    const uint32_t hbase = inclH - wantH, pbase = inclP - wantP;
+    // slot of this lane's heavy pair at `node` in the pair list (and in s_pf / s_pb)
+    auto slot_of = [&](uint32_t node) __attribute__((always_inline)) -> uint32_t {
+      return pbase + (uint32_t)__popcll(mH & ((1ull << node) - 1ull));
+    };
 
     P2_MARK(1);
-    // ---- 1. the heavy (lane, node) pairs: lane | node << 6 | segments << 12 | first record << 32
+    // ---- 1. the heavy (lane, node) pairs, up to four per step so that the re-reads of their meta
+    //         words (the segment counts) share a round trip
     if (run && n_pairs) {
-      uint32_t hcur = hbase, at = inclP - n_pairs;
-      for (uint32_t node = 1u; node < S.N; ++node) {
-        const uint32_t e = s_ent[node * 64u + lane];
-        if (!(e & EPV_P3_HEAVY)) continue;
-        const uint32_t K = segments_of(e, node);
-        plist[at++] = (unsigned long long)lane | ((unsigned long long)node << 6) | ((unsigned long long)K << 12) |
-                      ((unsigned long long)hcur << 32);
-        hcur += K;
+      unsigned long long h = mH;
+      uint32_t hcur = hbase, at = pbase;
+      while (h) {
+        uint32_t nd[4], K[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          nd[q] = h ? (uint32_t)(__ffsll((long long)h) - 1) : 0u;
+          if (h) h &= h - 1ull;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          K[q] = nd[q] ? (uint32_t)(S.meta[mbaseL + (uint64_t)(nd[q] - 1u) * n] & EPV_NJ_MASK) +
+                             (uint32_t)(S.meta[mbaseR + (uint64_t)(nd[q] - 1u) * n] & EPV_NJ_MASK) + 1u
+                       : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!nd[q]) continue;
+          const uint32_t leaf_state = (uint32_t)((mM ^ mMp) >> nd[q]) & 1u;
+          plist[at++] = (unsigned long long)lane | ((unsigned long long)nd[q] << 6) | ((unsigned long long)K[q] << 12) |
+                        ((unsigned long long)hcur << 32) | ((unsigned long long)leaf_state << 62);
+          hcur += K[q];
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- 2. one pair per lane: forward merge of the neighbours' jumps (Segment.cpp:35-79) into the
-    //         records' length and address fields.  Three passes of pairs at a time, stage by stage, so
+    //         records' length and address fields.  A few chunks of pairs at a time, stage by stage, so
     //         that their round trips (pair word -> meta words -> first jumps) overlap
-    for (uint32_t p0 = 0; p0 < totP; p0 += 3u * 64u) {
-      constexpr int NP = 3;
+    for (uint32_t p0 = 0; p0 < totP; p0 += (uint32_t)EPV_P3_NP * 64u) {
+      constexpr int NP = EPV_P3_NP;
       unsigned long long pr[NP];
       bool act[NP];
 #pragma unroll
@@ -190,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         if (!act[q]) continue;
-        const uint32_t owner = (uint32_t)pr[q] & 63u, node = ((uint32_t)pr[q] >> 6) & 63u, hcur = (uint32_t)(pr[q] >> 32);
+        const uint32_t owner = (uint32_t)pr[q] & 63u, node = ((uint32_t)pr[q] >> 6) & 63u, hcur = (uint32_t)(pr[q] >> 32) & 0xfffffu;
         const uint32_t nL = cL[q] & EPV_NJ_MASK, nR = cR[q] & EPV_NJ_MASK, K = nL + nR + 1u;
         uint32_t trip0 = 4u * (cL[q] >> EPV_INIT_SHIFT) + (cR[q] >> EPV_INIT_SHIFT), i = 0, j = 0;
         double seg_start = 0.0;
@@ -231,118 +259,92 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-
     P2_MARK(3);
-    // ---- 4. pruning, reverse pre-order (SingleSiteSampler.cpp:116-157).  The matrix entries of a heavy
-    //         branch are fetched four segments at a time, at the top of the node's iteration: one
-    //         round trip per branch (K <= 4) instead of one per segment
-    if (run) {
-      uint32_t hcur = hbase + heavy;      // one past the next record (records are consumed last to first)
-      for (uint32_t node = S.N - 1u; node >= 1u; --node) {
-        const uint32_t nw = s_node[node];
-        const uint32_t e = s_ent[node * 64u + lane];
-        uint32_t K = 0u, m = 0u;
-        double m00 = 0.0, m01 = 0.0, m10 = 0.0, m11 = 0.0, m20 = 0.0, m21 = 0.0, m30 = 0.0, m31 = 0.0;
-        if (e & EPV_P3_HEAVY) {
-          K = segments_of(e, node);
-          m = K < 4u ? K : 4u;
-          const double *r = list + (size_t)(hcur - 1u) * HREC;
-          m00 = r[0]; m01 = r[1];
-          m10 = r[-(int)HREC]; m11 = r[1 - (int)HREC];      // (K >= 2: the record exists)
-          if (m > 2u) { m20 = r[-2 * (int)HREC]; m21 = r[1 - 2 * (int)HREC]; }
-          if (m > 3u) { m30 = r[-3 * (int)HREC]; m31 = r[1 - 3 * (int)HREC]; }
-        }
-        double n0, n1;
-        if (EPV_P3_LEAF(nw)) {
-          const uint32_t leaf_state = ((e >> 2) ^ (e >> 3)) & 1u;
-          n0 = leaf_state ? 0.0 : 1.0;
-          n1 = leaf_state ? 1.0 : 0.0;
-        } else {
-          const double *a = s_stk + (size_t)EPV_P3_LEVEL(nw) * 128u + (size_t)lane * 2u;
-          n0 = a[0]; n1 = a[1];
-          double *qr = qrows + (size_t)EPV_P3_QROW(nw) * 128u + (size_t)lane * 2u;
-          qr[0] = n0; qr[1] = n1;
-        }
-        if (!(e & EPV_P3_HEAVY)) {
-          const double *t = s_tab + (size_t)((node - 1u) * 4u + (e & 3u)) * EPV_SEGTAB_DBL;
-          const double P00 = t[0], P11 = t[1];
-          const double P01 = 1.0 - P00, P10 = 1.0 - P11;
-          const double a = P00 * n0 + P01 * n1;
-          const double c = P10 * n0 + P11 * n1;
-          n0 = a; n1 = c;
-        } else {
-          uint32_t left = K;
-          for (;;) {
-            double *hr = list + (size_t)(hcur - 1u) * HREC;
-            // p[kk] = M[kk] p[kk + 1]; it takes the place of the matrix in the record
-#define EPV_P3_STEP(P00_, P11_, BACK)                                        \
-            {                                                                 \
-              const double P01 = 1.0 - (P00_), P10 = 1.0 - (P11_);            \
-              const double a = (P00_) * n0 + P01 * n1;                         \
-              const double c = P10 * n0 + (P11_) * n1;                         \
-              hr[-(int)((BACK) * HREC)] = a; hr[1 - (int)((BACK) * HREC)] = c; \
-              n0 = a; n1 = c;                                                  \
-            }
-            EPV_P3_STEP(m00, m01, 0u)
-            if (m > 1u) EPV_P3_STEP(m10, m11, 1u)
-            if (m > 2u) EPV_P3_STEP(m20, m21, 2u)
-            if (m > 3u) EPV_P3_STEP(m30, m31, 3u)
-#undef EPV_P3_STEP
-            hcur -= m;
-            left -= m;
-            if (left == 0u) break;
-            m = left < 4u ? left : 4u;
-            const double *r = list + (size_t)(hcur - 1u) * HREC;
-            m00 = r[0]; m01 = r[1];
-            if (m > 1u) { m10 = r[-(int)HREC]; m11 = r[1 - (int)HREC]; }
-            if (m > 2u) { m20 = r[-2 * (int)HREC]; m21 = r[1 - 2 * (int)HREC]; }
-            if (m > 3u) { m30 = r[-3 * (int)HREC]; m31 = r[1 - 3 * (int)HREC]; }
-          }
-        }
-        // p.front of this branch into its parent's product (a child of the root has no use for it:
-        // the root state is kept)
-        const uint32_t par = EPV_P3_PARENT(nw);
-        if (par != 0u) {
-          double *acc = s_stk + (size_t)EPV_P3_LEVEL(s_node[par]) * 128u + (size_t)lane * 2u;
-          if (EPV_P3_LASTCHILD(nw)) { acc[0] = n0; acc[1] = n1; }
-          else { acc[0] = acc[0] * n0; acc[1] = acc[1] * n1; }
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
 
-    P2_MARK(4);
-    // ---- 5. the heavy branches' end states for BOTH start states, one pair per lane.  The uniforms
-    //         of a segment are fixed, so the chain of end states along a branch is a function of the
-    //         start state alone: evaluating it for 0 and for 1 here, densely, leaves the sequential
-    //         walk over the tree below with a table lookup where the first kernel iterated
-    //         max_lanes(K) times over a division with a tenth of the lanes busy.  The words of
-    //         sampled states for both start states wait in the first record's PT slots, which this
-    //         pass has used by then.  (More than 64 segments: the walk's own loop, EPV_P3_SLOW.)
-    for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
-      const uint32_t pidx = p0 + (uint32_t)lane;
-      if (pidx < totP) {
+    // The heavy pairs of one level of the tree, one pair per lane: the branch's pruning chain
+    // p[k] = M[k] p[k + 1] from q of its node, then the chain of end states for both start states.
+    // level 0 = the leaf branches (q is the observed state), d >= 1 = the internal nodes of depth d
+    // (q from the row the nodes' pass has just written).
+    auto pair_pass = [&](uint32_t level) __attribute__((always_inline)) {
+      for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
+        const uint32_t pidx = p0 + (uint32_t)lane;
+        if (pidx >= totP) continue;
         const unsigned long long pr = plist[pidx];
-        const uint32_t owner = (uint32_t)pr & 63u, node = ((uint32_t)pr >> 6) & 63u, K = ((uint32_t)pr >> 12) & 0xfffffu;
-        const uint32_t hrec0 = (uint32_t)(pr >> 32);
-        if (K <= 64u) {
-          const uint32_t nw = s_node[node];
-          const uint32_t e = s_ent[node * 64u + owner];
-          double q0, q1;
-          if (EPV_P3_LEAF(nw)) {
-            const uint32_t leaf_state = ((e >> 2) ^ (e >> 3)) & 1u;
-            q0 = leaf_state ? 0.0 : 1.0;
-            q1 = leaf_state ? 1.0 : 0.0;
-          } else {
-            const double *qr = qrows + (size_t)EPV_P3_QROW(nw) * 128u + (size_t)owner * 2u;
-            q0 = qr[0]; q1 = qr[1];
+        const uint32_t owner = (uint32_t)pr & 63u, node = ((uint32_t)pr >> 6) & 63u, K = ((uint32_t)(pr >> 12)) & 0xfffffu;
+        const uint32_t hrec0 = (uint32_t)(pr >> 32) & 0xfffffu;
+        const uint32_t nw = s_tree[node];
+        if ((EPV_P3_LEAF(nw) ? 0u : EPV_P3_DEPTH(nw)) != level) continue;
+        double q0, q1;
+        if (EPV_P3_LEAF(nw)) {
+          const uint32_t leaf_state = (uint32_t)(pr >> 62) & 1u;
+          q0 = leaf_state ? 0.0 : 1.0;
+          q1 = leaf_state ? 1.0 : 0.0;
+        } else {
+          const double *qr = qrows + (size_t)EPV_P3_QROW(nw) * 128u + (size_t)owner * 2u;
+          q0 = qr[0]; q1 = qr[1];
+        }
+        double *h0 = list + (size_t)hrec0 * HREC;
+        uint32_t prevA = 0u, prevB = 1u;            // chains from start state 0 and from start state 1
+        bool cleanA = true, cleanB = true;
+        unsigned long long wA = 0ull, wB = 0ull;
+        double pf0, pf1;
+        if (K <= EPV_P3_KREG) {
+          // everything from registers: the records in one batch of loads
+          double R[EPV_P3_KREG][8];
+#pragma unroll
+          for (int k = 0; k < (int)EPV_P3_KREG; ++k) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) R[k][f] = 0.0;
+            if ((uint32_t)k < K) {
+#pragma unroll
+              for (int f = 0; f < 8; ++f) R[k][f] = h0[(size_t)k * HREC + f];
+            }
           }
-          double *hr = list + (size_t)hrec0 * HREC;
-          uint32_t prevA = 0u, prevB = 1u;            // chains from start state 0 and from start state 1
-          bool cleanA = true, cleanB = true;
-          unsigned long long wA = 0ull, wB = 0ull;
-          double pk0 = hr[0], pk1 = hr[1];
+          double p[EPV_P3_KREG + 1][2];
+          p[EPV_P3_KREG][0] = q0; p[EPV_P3_KREG][1] = q1;
+#pragma unroll
+          for (int k = (int)EPV_P3_KREG - 1; k >= 0; --k) {
+            if ((uint32_t)k < K) {
+              const double n0 = ((uint32_t)k + 1u == K) ? q0 : p[k + 1][0], n1 = ((uint32_t)k + 1u == K) ? q1 : p[k + 1][1];
+              const double P00 = R[k][0], P11 = R[k][1];
+              const double P01 = 1.0 - P00, P10 = 1.0 - P11;
+              p[k][0] = P00 * n0 + P01 * n1;
+              p[k][1] = P10 * n0 + P11 * n1;
+            } else { p[k][0] = 0.0; p[k][1] = 0.0; }
+          }
+          pf0 = p[0][0]; pf1 = p[0][1];
+#pragma unroll
+          for (int k = 0; k < (int)EPV_P3_KREG; ++k) {
+            if ((uint32_t)k < K) {
+              const bool last_seg = ((uint32_t)k + 1u == K);
+              const double nxt0 = last_seg ? q0 : p[k + 1][0];
+              const double pk0 = p[k][0], pk1 = p[k][1];
+              const double PT00 = R[k][2], PT10 = R[k][3], nb0 = R[k][4], nb1 = R[k][5], u_end = R[k][6], u_first = R[k][7];
+              const double p0A = (prevA ? PT10 : PT00) * nxt0 / (prevA ? pk1 : pk0);
+              const double p0B = (prevB ? PT10 : PT00) * nxt0 / (prevB ? pk1 : pk0);
+              const uint32_t sA = (u_end > p0A) ? 1u : 0u, sB = (u_end > p0B) ? 1u : 0u;
+              cleanA = cleanA && (sA == prevA) && (1.0 - u_first < (prevA ? nb1 : nb0));
+              cleanB = cleanB && (sB == prevB) && (1.0 - u_first < (prevB ? nb1 : nb0));
+              wA |= (unsigned long long)sA << k;
+              wB |= (unsigned long long)sB << k;
+              prevA = sA; prevB = sB;
+            }
+          }
+        } else {
+          // a long branch: the partials through the records (they take the place of the matrices)
+          double n0 = q0, n1 = q1;
+          for (uint32_t kk = K; kk-- > 0u;) {
+            double *hr = h0 + (size_t)kk * HREC;
+            const double P00 = hr[0], P11 = hr[1];
+            const double P01 = 1.0 - P00, P10 = 1.0 - P11;
+            const double a = P00 * n0 + P01 * n1;
+            const double c = P10 * n0 + P11 * n1;
+            hr[0] = a; hr[1] = c;
+            n0 = a; n1 = c;
+          }
+          pf0 = n0; pf1 = n1;
+          const double *hr = h0;
+          double pk0 = pf0, pk1 = pf1;
           for (uint32_t k = 0; k < K; ++k) {
             const bool last_seg = (k + 1u == K);
             const double nxt0 = last_seg ? q0 : hr[HREC], nxt1 = last_seg ? q1 : hr[HREC + 1u];
@@ -352,139 +354,226 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
             const uint32_t sA = (u_end > p0A) ? 1u : 0u, sB = (u_end > p0B) ? 1u : 0u;
             cleanA = cleanA && (sA == prevA) && (1.0 - u_first < (prevA ? nb1 : nb0));
             cleanB = cleanB && (sB == prevB) && (1.0 - u_first < (prevB ? nb1 : nb0));
-            wA |= (unsigned long long)sA << k;
-            wB |= (unsigned long long)sB << k;
+            if (k < 64u) { wA |= (unsigned long long)sA << k; wB |= (unsigned long long)sB << k; }
             prevA = sA; prevB = sB;
             pk0 = nxt0; pk1 = nxt1;
             hr += HREC;
           }
-          double *h0 = list + (size_t)hrec0 * HREC;
-          h0[2] = epv_u2d(wA);
-          h0[3] = epv_u2d(wB);
-          s_ent[node * 64u + owner] = (uint16_t)((e & 0x0fffu) | (prevA << 12) | ((cleanA ? 1u : 0u) << 13) |
-                                                 (prevB << 14) | ((cleanB ? 1u : 0u) << 15));
         }
+        // the words of sampled states wait in the first record's PT slots (used by now) for the pass
+        // behind the downward walk, which knows the start state; a branch of more than 64 segments
+        // keeps its record and is walked again there
+        if (K <= 64u) { h0[2] = epv_u2d(wA); h0[3] = epv_u2d(wB); }
+        s_pf[2u * pidx] = pf0; s_pf[2u * pidx + 1u] = pf1;
+        s_pb[pidx] = (uint8_t)(prevA | ((cleanA ? 1u : 0u) << 1) | (prevB << 2) | ((cleanB ? 1u : 0u) << 3) |
+                               ((K == 2u || K >= 4u) ? 16u : 0u) | (K >= 3u ? 32u : 0u));
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    // q of a leaf: the observed state (the end state of the site's current path)
+    auto leaf_q = [&](uint32_t node, double &q0, double &q1) __attribute__((always_inline)) {
+      const uint32_t leaf_state = (uint32_t)((mM ^ mMp) >> node) & 1u;
+      q0 = leaf_state ? 0.0 : 1.0;
+      q1 = leaf_state ? 1.0 : 0.0;
+    };
 
-    P2_MARK(5);
-    // ---- 6. downward sampling of the segment END STATES (:180-255); the jump times are drawn by
-    //         epv_mh_jumps_kernel for the dirty branches only.  q of the next internal node is
-    //         requested one node ahead.
-    unsigned long long dirty = 0ull, multi = 0ull, deep = 0ull;
-    bool ident = true;
-    const uint32_t root_state = run ? ((uint32_t)s_ent[64u + lane] >> 2) & 1u : 0u;
-    if (run) {
-      uint32_t hcur = hbase;
-      double qn0 = 0.0, qn1 = 0.0;
-      {
-        const uint32_t nw1 = s_node[1];
-        if (!EPV_P3_LEAF(nw1)) { const double *qr = qrows + (size_t)EPV_P3_QROW(nw1) * 128u + (size_t)lane * 2u; qn0 = qr[0]; qn1 = qr[1]; }
-      }
-      for (uint32_t node = 1u; node < S.N; ++node) {
-        const uint32_t b = node - 1u;
-        const uint32_t nw = s_node[node];
-        const uint32_t e = s_ent[node * 64u + lane];
-        const uint32_t par = EPV_P3_PARENT(nw);
-        const uint32_t start_state = (par == 0u) ? root_state : ((uint32_t)s_ent[par * 64u + lane] >> 6) & 1u;
-        double q0 = qn0, q1 = qn1;
-        if (EPV_P3_LEAF(nw)) {
-          const uint32_t leaf_state = ((e >> 2) ^ (e >> 3)) & 1u;
-          q0 = leaf_state ? 0.0 : 1.0;
-          q1 = leaf_state ? 1.0 : 0.0;
-        }
-        if (node + 1u < S.N) {
-          const uint32_t nwn = s_node[node + 1u];
-          if (!EPV_P3_LEAF(nwn)) { const double *qr = qrows + (size_t)EPV_P3_QROW(nwn) * 128u + (size_t)lane * 2u; qn0 = qr[0]; qn1 = qr[1]; }
-        }
-        uint32_t prev = start_state, K = 1u;
-        bool clean;
-        if (!(e & EPV_P3_HEAVY)) {
-          const double *t = s_tab + (size_t)(b * 4u + (e & 3u)) * EPV_SEGTAB_DBL;
-          const double P00 = t[0], P11 = t[1];
-          const double P01 = 1.0 - P00, P10 = 1.0 - P11;
-          const double pk0 = P00 * q0 + P01 * q1;     // p.front, as pruning computed it
-          const double pk1 = P10 * q0 + P11 * q1;
-          const double PT0 = prev ? t[3] : t[2];
-          const double nb = prev ? t[5] : t[4];
-          const epv_block2 blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, 0u, 0u, 0u);
-          const double p0 = PT0 * q0 / (prev ? pk1 : pk0);
-          const uint32_t sampled = (blk.d0 > p0) ? 1u : 0u;
-          clean = (sampled == prev) && (1.0 - blk.d1 < nb);
-          if (!clean) S.prop_states[((uint64_t)b * S.phase_cap + tid) * S.W] = (unsigned long long)sampled;
-          prev = sampled;
-        } else if (!(e & EPV_P3_SLOW)) {
-          K = segments_of(e, node);
-          hcur += K;
-          clean = (e >> (start_state ? 15u : 13u)) & 1u;
-          prev = (e >> (start_state ? 14u : 12u)) & 1u;
-        } else {
-          K = segments_of(e, node);
-          clean = true;
-          unsigned long long word = 0ull;
-          uint64_t *states = S.prop_states + ((uint64_t)b * S.phase_cap + tid) * S.W;
-          const double *hr = list + (size_t)hcur * HREC;
-          double pk0 = hr[0], pk1 = hr[1];
-          for (uint32_t k = 0; k < K; ++k) {
-            const bool last_seg = (k + 1u == K);
-            const double nxt0 = last_seg ? q0 : hr[HREC], nxt1 = last_seg ? q1 : hr[HREC + 1u];
-            const double PT0 = prev ? hr[3] : hr[2];
-            const double nb = prev ? hr[5] : hr[4];
-            const double p0 = PT0 * nxt0 / (prev ? pk1 : pk0);
-            const uint32_t sampled = (hr[6] > p0) ? 1u : 0u;
-            clean = clean && (sampled == prev) && (1.0 - hr[7] < nb);
-            word |= (unsigned long long)sampled << (k & 63u);
-            if ((k & 63u) == 63u) { states[k >> 6] = word; word = 0ull; }
-            prev = sampled;
-            pk0 = nxt0; pk1 = nxt1;
-            hr += HREC;
+    // ---- 4. pruning (SingleSiteSampler.cpp:116-157), deepest level first.  A level: q of its internal
+    //         nodes from their children's p.front -- a heavy child's from its pair lane, any other
+    //         recomputed from the child's q and the matrix table -- then the level's heavy pairs.
+    pair_pass(0u);
+    for (uint32_t d = depth; d-- > 1u;) {
+      if (run) {
+        const uint32_t i0 = s_upstart[d + 1u], i1 = s_upstart[d];     // (deepest first: level d + 1 precedes level d)
+        for (uint32_t ib = i0; ib < i1; ib += 4u) {
+          // the q rows of up to eight internal children in one batch
+          double cq[4][2][2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) { cq[j][w][0] = 0.0; cq[j][w][1] = 0.0; }
+            if (ib + (uint32_t)j < i1) {
+              const uint32_t nw = s_tree[s_up[ib + j]];
+#pragma unroll
+              for (int w = 0; w < 2; ++w) {
+                const uint32_t c = w ? EPV_P3_CHILD2(nw) : EPV_P3_CHILD1(nw);
+                if (c == 0u) continue;
+                const uint32_t cw = s_tree[c];
+                if (!EPV_P3_LEAF(cw) && !((mH >> c) & 1ull)) {
+                  const double *qr = qrows + (size_t)EPV_P3_QROW(cw) * 128u + (size_t)lane * 2u;
+                  cq[j][w][0] = qr[0]; cq[j][w][1] = qr[1];
+                }
+              }
+            }
           }
-          hcur += K;
-          if ((K & 63u) && !clean) states[(K - 1u) >> 6] = word;   // only a dirty branch is read back
+#pragma unroll 1
+          for (uint32_t j = 0; j < 4u; ++j) {
+            if (ib + j >= i1) break;
+            const uint32_t P = s_up[ib + j];
+            const uint32_t nw = s_tree[P];
+            double a0 = 1.0, a1 = 1.0;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              const uint32_t c = w ? EPV_P3_CHILD2(nw) : EPV_P3_CHILD1(nw);
+              if (c == 0u) continue;
+              double f0, f1;
+              if ((mH >> c) & 1ull) {
+                const uint32_t sl = slot_of(c);
+                f0 = s_pf[2u * sl]; f1 = s_pf[2u * sl + 1u];
+              } else {
+                double q0 = j == 0u ? cq[0][w][0] : j == 1u ? cq[1][w][0] : j == 2u ? cq[2][w][0] : cq[3][w][0];
+                double q1 = j == 0u ? cq[0][w][1] : j == 1u ? cq[1][w][1] : j == 2u ? cq[2][w][1] : cq[3][w][1];
+                if (EPV_P3_LEAF(s_tree[c])) leaf_q(c, q0, q1);
+                const uint32_t ctx = (uint32_t)(((mL >> c) & 1ull) << 1) | (uint32_t)((mR >> c) & 1ull);
+                const double *t = s_tab + (size_t)((c - 1u) * 4u + ctx) * EPV_SEGTAB_DBL;
+                const double P00 = t[0], P11 = t[1];
+                const double P01 = 1.0 - P00, P10 = 1.0 - P11;
+                f0 = P00 * q0 + P01 * q1;
+                f1 = P10 * q0 + P11 * q1;
+              }
+              a0 *= f0;     // q *= p.front of the child, children in pre-order (:121-127)
+              a1 *= f1;
+            }
+            double *qr = qrows + (size_t)EPV_P3_QROW(nw) * 128u + (size_t)lane * 2u;
+            qr[0] = a0; qr[1] = a1;
+          }
         }
-        // proposal end state for the children (bit 6), "dirty" for the pair pass below (bit 7 of a heavy branch)
-        s_ent[node * 64u + lane] = (uint16_t)((e & ~EPV_P3_SLOW) | (prev << 6) |
-                                              ((e & EPV_P3_HEAVY) && !(e & EPV_P3_SLOW) && !clean ? EPV_P3_SLOW : 0u));
-        // same as the current path?  (no jumps on either, same start state)
-        ident = ident && clean && !(e & 16u) && ((e >> 2) & 1u) == start_state;
-        if (!clean) {
-          dirty |= 1ull << b;
-          if (K == 2u || K >= 4u) multi |= 1ull << b;   // four buckets by segment count
-          if (K >= 3u) deep |= 1ull << b;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      pair_pass(d);
+    }
+    P2_MARK(4);
+
+    // ---- 5. downward sampling of the segment END STATES (:180-255), level by level from the root;
+    //         the jump times are drawn by epv_mh_jumps_kernel for the dirty branches only
+    unsigned long long mEnd = 0ull, dirty = 0ull, multi = 0ull, deep = 0ull;
+    bool ident = true;
+    if (run) {
+      for (uint32_t d = 1u; d <= depth; ++d) {
+        const uint32_t i0 = s_dnstart[d], i1 = s_dnstart[d + 1u];
+        for (uint32_t ib = i0; ib < i1; ib += 4u) {
+          double cq[4][2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            cq[j][0] = 0.0; cq[j][1] = 0.0;
+            if (ib + (uint32_t)j < i1) {
+              const uint32_t c = s_dn[ib + j];
+              const uint32_t cw = s_tree[c];
+              if (!EPV_P3_LEAF(cw) && !((mH >> c) & 1ull)) {
+                const double *qr = qrows + (size_t)EPV_P3_QROW(cw) * 128u + (size_t)lane * 2u;
+                cq[j][0] = qr[0]; cq[j][1] = qr[1];
+              }
+            }
+          }
+          // (one node at a time: four interleaved Philox blocks cost more registers than they hide latency)
+#pragma unroll 1
+          for (uint32_t j = 0; j < 4u; ++j) {
+            if (ib + j >= i1) break;
+            const uint32_t node = s_dn[ib + j], b = node - 1u;
+            const uint32_t nw = s_tree[node];
+            const uint32_t par = EPV_P3_PARENT(nw);
+            const uint32_t start_state = (par == 0u) ? root_state : (uint32_t)(mEnd >> par) & 1u;
+            uint32_t prev;
+            bool clean, b_multi = false, b_deep = false;
+            if (!((mH >> node) & 1ull)) {
+              double q0 = j == 0u ? cq[0][0] : j == 1u ? cq[1][0] : j == 2u ? cq[2][0] : cq[3][0];
+              double q1 = j == 0u ? cq[0][1] : j == 1u ? cq[1][1] : j == 2u ? cq[2][1] : cq[3][1];
+              if (EPV_P3_LEAF(nw)) leaf_q(node, q0, q1);
+              const uint32_t ctx = (uint32_t)(((mL >> node) & 1ull) << 1) | (uint32_t)((mR >> node) & 1ull);
+              const double *t = s_tab + (size_t)(b * 4u + ctx) * EPV_SEGTAB_DBL;
+              const double P00 = t[0], P11 = t[1];
+              const double P01 = 1.0 - P00, P10 = 1.0 - P11;
+              const double pk0 = P00 * q0 + P01 * q1;     // p.front, as pruning computed it
+              const double pk1 = P10 * q0 + P11 * q1;
+              const double PT0 = start_state ? t[3] : t[2];
+              const double nb = start_state ? t[5] : t[4];
+              const epv_block2 blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, 0u, 0u, 0u);
+              const double p0 = PT0 * q0 / (start_state ? pk1 : pk0);
+              prev = (blk.d0 > p0) ? 1u : 0u;
+              clean = (prev == start_state) && (1.0 - blk.d1 < nb);
+              if (!clean) S.prop_states[((uint64_t)b * S.phase_cap + tid) * S.W] = (unsigned long long)prev;
+            } else {
+              const uint32_t r = s_pb[slot_of(node)];
+              prev = (r >> (start_state ? 2u : 0u)) & 1u;
+              clean = (r >> (start_state ? 3u : 1u)) & 1u;
+              b_multi = (r >> 4) & 1u; b_deep = (r >> 5) & 1u;
+            }
+            mEnd |= (unsigned long long)prev << node;     // proposal end state for the children
+            // same as the current path?  (no jumps on either, same start state)
+            ident = ident && clean && !((mMj >> node) & 1ull) && ((uint32_t)(mM >> node) & 1u) == start_state;
+            if (!clean) {
+              dirty |= 1ull << b;
+              if (b_multi) multi |= 1ull << b;   // four buckets by segment count
+              if (b_deep) deep |= 1ull << b;
+            }
+          }
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- 7. the words of sampled states of the dirty heavy branches, one pair per lane again
+    P2_MARK(5);
+    // ---- 6. the words of sampled states of the dirty heavy branches, one pair per lane again
     for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
       const uint32_t pidx = p0 + (uint32_t)lane;
+      const unsigned long long pr = pidx < totP ? plist[pidx] : 0ull;
+      const uint32_t owner = (uint32_t)pr & 63u, node = ((uint32_t)pr >> 6) & 63u;
+      const unsigned long long oEnd = (unsigned long long)__shfl((uint32_t)mEnd, (int)owner) | ((unsigned long long)__shfl((uint32_t)(mEnd >> 32), (int)owner) << 32);
+      const uint32_t oRoot = (uint32_t)__shfl((int)root_state, (int)owner);
       if (pidx < totP) {
-        const unsigned long long pr = plist[pidx];
-        const uint32_t owner = (uint32_t)pr & 63u, node = ((uint32_t)pr >> 6) & 63u;
-        const uint32_t e = s_ent[node * 64u + owner];
-        if (e & EPV_P3_SLOW) {           // (bit 7 now: heavy, at most 64 segments, dirty)
-          const uint32_t par = EPV_P3_PARENT(s_node[node]);
-          const uint32_t st = (par == 0u) ? ((uint32_t)s_ent[64u + owner] >> 2) & 1u : ((uint32_t)s_ent[par * 64u + owner] >> 6) & 1u;
-          const double *h0 = list + (size_t)(uint32_t)(pr >> 32) * HREC;
-          S.prop_states[((uint64_t)(node - 1u) * S.phase_cap + (tid - (uint32_t)lane + owner)) * S.W] = epv_d2u(h0[2u + st]);
+        const uint32_t K = ((uint32_t)(pr >> 12)) & 0xfffffu, hrec0 = (uint32_t)(pr >> 32) & 0xfffffu;
+        const uint32_t nw = s_tree[node];
+        const uint32_t par = EPV_P3_PARENT(nw);
+        const uint32_t st = (par == 0u) ? oRoot : (uint32_t)(oEnd >> par) & 1u;
+        const uint32_t r = s_pb[pidx];
+        const bool clean = (r >> (st ? 3u : 1u)) & 1u;
+        if (!clean) {
+          uint64_t *states = S.prop_states + ((uint64_t)(node - 1u) * S.phase_cap + (tid - (uint32_t)lane + owner)) * S.W;
+          const double *h0 = list + (size_t)hrec0 * HREC;
+          if (K <= 64u) {
+            states[0] = epv_d2u(h0[2u + st]);
+          } else {
+            // more than 64 segments: walk the branch again from its start state, word by word
+            double q0, q1;
+            if (EPV_P3_LEAF(nw)) {
+              const uint32_t leaf_state = (uint32_t)(pr >> 62) & 1u;
+              q0 = leaf_state ? 0.0 : 1.0;
+              q1 = leaf_state ? 1.0 : 0.0;
+            } else {
+              const double *qr = qrows + (size_t)EPV_P3_QROW(nw) * 128u + (size_t)owner * 2u;
+              q0 = qr[0]; q1 = qr[1];
+            }
+            uint32_t prev = st;
+            unsigned long long word = 0ull;
+            const double *hr = h0;
+            double pk0 = hr[0], pk1 = hr[1];
+            for (uint32_t k = 0; k < K; ++k) {
+              const bool last_seg = (k + 1u == K);
+              const double nxt0 = last_seg ? q0 : hr[HREC], nxt1 = last_seg ? q1 : hr[HREC + 1u];
+              const double p0 = (prev ? hr[3] : hr[2]) * nxt0 / (prev ? pk1 : pk0);
+              const uint32_t sampled = (hr[6] > p0) ? 1u : 0u;
+              word |= (unsigned long long)sampled << (k & 63u);
+              if ((k & 63u) == 63u) { states[k >> 6] = word; word = 0ull; }
+              prev = sampled;
+              pk0 = nxt0; pk1 = nxt1;
+              hr += HREC;
+            }
+            if (K & 63u) states[(K - 1u) >> 6] = word;
+          }
         }
       }
     }
-    P2_MARK(6);
     epv_flush_tasks(S, counters, dirty, multi, deep, B - 1u, site, lane, my_shard);
+    P2_MARK(6);
 
-    // ---- 8. hand-over.  A proposal equal to the current path is accepted with probability one and
+    // ---- 7. hand-over.  A proposal equal to the current path is accepted with probability one and
     //         changes neither the paths nor the cached likelihoods: count it and be done.  Everything
     //         else: start states of the proposal's branches into the other buffer, and the site onto
     //         the accept list of this wave's shard.
     const bool to_list = run && !ident;
     if (to_list) {
-      for (uint32_t node = 1u; node < S.N; ++node) {
-        const uint32_t par = EPV_P3_PARENT(s_node[node]);
-        const uint32_t st = (par == 0u) ? root_state : ((uint32_t)s_ent[par * 64u + lane] >> 6) & 1u;
+      for (uint32_t node = 1u; node < N; ++node) {
+        const uint32_t par = EPV_P3_PARENT(s_tree[node]);
+        const uint32_t st = (par == 0u) ? root_state : (uint32_t)(mEnd >> par) & 1u;
         S.meta[(selM ? 0ull : Bn) + (uint64_t)(node - 1u) * n + site] = (epv_meta_t)(st << EPV_INIT_SHIFT);
       }
       S.prop_flag[tid] = 0u;
@@ -505,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void epv_mh_propose3_kernel(
         atomicAdd(&counters[EPV_CNT_IDX(EPV_CNT_ACCEPT, my_shard)], (unsigned long long)__popcll(am));
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();     // (a later round reuses the pair list and the records)
+    __builtin_amdgcn_wave_barrier();     // (a later round reuses the pair list, the rows and the records)
     pending = pending && !run;
     P2_MARK(7);
   }
