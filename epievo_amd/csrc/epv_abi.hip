@@ -657,8 +657,20 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   if (list_mode) {
     // the listed sites (proposal differs from the current path) per shard: typically ~30 % of the
     // colour; the grid covers half of the worst case and strides over the rest
+    // (on a large tree nearly every site is listed -- one clean proposal in thirty branches is rare --
+    // and a block that strides twice runs two of the kernel's long dependent chains back to back)
     const uint64_t per_shard = (threads + EPV_SHARDS - 1u) / EPV_SHARDS;
-    const unsigned ax = (unsigned)std::max<uint64_t>(1u, (per_shard / 2u + 255u) / 256u);
+    static const int acc_full = std::getenv("EPV_ACCEPT_FULL_GRID") ? std::atoi(std::getenv("EPV_ACCEPT_FULL_GRID")) : -1;
+    const bool full = acc_full >= 0 ? acc_full != 0 : c->S.B > 8u;
+    const unsigned ax = (unsigned)std::max<uint64_t>(1u, ((full ? per_shard : per_shard / 2u) + 255u) / 256u);
+    // large trees (no room for the meta cache): a lane per (site, triple), branches in groups (epv_accept3.h)
+    static const int acc_v3 = std::getenv("EPV_ACCEPT_V3") ? std::atoi(std::getenv("EPV_ACCEPT_V3")) : -1;
+    if (acc_v3 >= 0 ? acc_v3 != 0 : !meta_cache) {
+      const unsigned ax3 = (unsigned)std::max<uint64_t>(1u, (per_shard + 4u * EPV_ACC3_SITES - 1u) / (4u * EPV_ACC3_SITES));
+      hipLaunchKernelGGL(epv_mh_accept3_kernel, dim3(ax3, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N), c->stream,
+                         c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo,
+                         own_hi, c->d_counters, list_mode);
+    } else
     hipLaunchKernelGGL(epv_mh_accept_kernel, dim3(ax, EPV_SHARDS), dim3(256), acc_lds, c->stream,
                        c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo,
                        own_hi, c->d_counters, list_mode, meta_cache);

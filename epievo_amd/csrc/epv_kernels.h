@@ -1103,6 +1103,7 @@ __global__ __launch_bounds__(256, EPV_ACCEPT_WAVES) void epv_mh_accept_kernel(
 // the second proposal kernel; its fused variant runs the search, assembly and acceptance above
 #include "epv_propose2.h"
 #include "epv_propose3.h"
+#include "epv_accept3.h"
 
 // =========================================================================
 //  initialize_paths_indep (src/prog/epievo_sim_pairwise.cpp:62-110) on the device: every

@@ -261,6 +261,10 @@ _SEPARATE = {"EPV_FUSED_PHASE": "0"}      # small launches take the fused phase 
                                        ("bal16", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
                                        ("bal16", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="1", EPV_P3_MIN_LIST="1")),
                                        ("tree", 20011, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
+                                       ("bal16", 2000, dict(_SEPARATE, EPV_ACCEPT_V3="0")),
+                                       ("tree", 20011, dict(_SEPARATE, EPV_ACCEPT_V3="1")),
+                                       ("cat6", 3000, dict(_SEPARATE, EPV_ACCEPT_V3="1", EPV_SEG_JUMPS="1")),
+                                       ("pair", 9000, dict(_SEPARATE, EPV_ACCEPT_V3="1")),
                                        ("cat6", 3000, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
                                        ("star4", 3000, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
                                        ("pair", 9000, dict(_SEPARATE, EPV_PROPOSE_V3="1", EPV_P3_MIN_LIST="1")),
