@@ -327,6 +327,15 @@ int plan_p3(epv_ctx *c) {
   tab.insert(tab.end(), upstart.begin(), upstart.end());
   tab.insert(tab.end(), dn.begin(), dn.end());
   tab.insert(tab.end(), dnstart.begin(), dnstart.end());
+  for (uint32_t g = 0; g < max_depth; ++g) {            // pair groups: leaves, then internal nodes by depth
+    uint64_t m = 0;
+    for (uint32_t node = 1; node < N; ++node) {
+      const bool leaf = c->subtree[node] == 1u;
+      if (g == 0u ? leaf : (!leaf && depth[node] == g)) m |= 1ull << node;
+    }
+    tab.push_back((uint32_t)m);
+    tab.push_back((uint32_t)(m >> 32));
+  }
   const double lam = 2.0 * c->kbar;
   const double heavy_per_branch = (1.0 + lam) - std::exp(-lam);
   const uint64_t worst_heavy = (uint64_t)B * (2u * C + 1u);
@@ -347,7 +356,7 @@ int plan_p3(epv_ctx *c) {
   if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 512u * sizeof(uint32_t)));
   HIP_TRY(c, hipMemcpy(c->d_nodetab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * EPV_SEGTAB_DBL * 8u + (tab.size() + 1u) / 2u * 8u;
-  const size_t per_wave = ((size_t)EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u) * 8u;     // pair results: p.front, result bits
+  const size_t per_wave = ((size_t)EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u + (max_depth * 64u * 2u + 7u) / 8u + (max_depth + 3u) / 2u) * 8u;   // pair results, group offsets
   c->p3_lds = shared + 4u * per_wave;
   c->p3_list_cap = (uint32_t)list_cap;
   c->p3_qrows = qrows;

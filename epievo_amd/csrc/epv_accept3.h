@@ -41,7 +41,7 @@ __device__ __forceinline__ void merge3_pre(const PathRef &L, const PathRef &M, c
 }
 
 #ifndef EPV_ACC3_GROUP
-#define EPV_ACC3_GROUP 5   /* branches per batch of loads */
+#define EPV_ACC3_GROUP 4   /* branches per batch of loads (5 or 6: more registers than 4 waves per SIMD have, no faster) */
 #endif
 
 // path_log_likelihood (SingleSiteSampler.cpp:374-391) of one triple, branches in groups
@@ -98,8 +98,11 @@ __device__ __forceinline__ double triple_llh_grouped(const EpvDev &S, const doub
 }
 
 #define EPV_ACC3_SITES 21u   /* sites per wave: three lanes each, lane 63 idles */
+#ifndef EPV_ACC3_MINBLOCKS
+#define EPV_ACC3_MINBLOCKS 4
+#endif
 
-__global__ __launch_bounds__(256, 4) void epv_mh_accept3_kernel(
+__global__ __launch_bounds__(256, EPV_ACC3_MINBLOCKS) void epv_mh_accept3_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first, uint64_t last,
     uint64_t own_first, uint64_t own_last, unsigned long long *counters, uint32_t list_mode) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];

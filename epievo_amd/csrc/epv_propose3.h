@@ -54,7 +54,7 @@
 #define EPV_P3_NP 2      /* chunks of 64 pairs the merge pass interleaves */
 #endif
 #ifndef EPV_P3_MINBLOCKS
-#define EPV_P3_MINBLOCKS 2   /* blocks of four waves per CU the register allocation aims for */
+#define EPV_P3_MINBLOCKS 3   /* blocks of four waves per CU the register allocation aims for (<= 168 VGPRs) */
 #endif
 template <bool DUMMY>
 __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
@@ -74,17 +74,26 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
   // tree tables: node words [N], internal nodes deepest level first [n_up] with level starts
   // [depth + 2] (level d from s_upstart[d + 1] to s_upstart[d]), all nodes but the root by depth
   // [N - 1] with level starts [depth + 2] (level d from s_dnstart[d] to s_dnstart[d + 1])
-  const uint32_t tree_words = N + n_up + (depth + 2u) + (N - 1u) + (depth + 2u);
+  // and the node masks of the pair groups [2 * depth] (group 0 = leaves, d = internal nodes of depth d)
+  const uint32_t tree_words = N + n_up + (depth + 2u) + (N - 1u) + (depth + 2u) + 2u * depth;
   const uint32_t tree_dbl = (tree_words + 1u) / 2u;
-  const uint32_t wave_dbl = EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u;
+  // per wave: p.front and result bits of the pairs, each lane's first slot per group, the groups' starts
+  const uint32_t goff_dbl = (depth * 64u * 2u + 7u) / 8u, gstart_dbl = (depth + 2u + 1u) / 2u;
+  const uint32_t wave_dbl = EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u + goff_dbl + gstart_dbl;
   const uint32_t wave_id = threadIdx.x >> 6;
   double *s_const = s_mem;
   double *s_tab = s_mem + const_dbl;
   uint32_t *s_tree = reinterpret_cast<uint32_t *>(s_mem + const_dbl + tab_dbl);
   const uint32_t *s_up = s_tree + N, *s_upstart = s_up + n_up;
   const uint32_t *s_dn = s_upstart + (depth + 2u), *s_dnstart = s_dn + (N - 1u);
+  const uint32_t *s_gmask = s_dnstart + (depth + 2u);
   double *s_pf = s_mem + const_dbl + tab_dbl + tree_dbl + (size_t)wave_id * wave_dbl;
   uint8_t *s_pb = reinterpret_cast<uint8_t *>(s_pf + EPV_P3_PCAP * 2u);
+  uint16_t *s_goff = reinterpret_cast<uint16_t *>(s_pf + EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u);
+  uint32_t *s_gstart = reinterpret_cast<uint32_t *>(s_pf + EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u + goff_dbl);
+  auto group_mask = [&](uint32_t g) __attribute__((always_inline)) -> unsigned long long {
+    return (unsigned long long)s_gmask[2u * g] | ((unsigned long long)s_gmask[2u * g + 1u] << 32);
+  };
   const int lane = epv_lane();
   const uint32_t my_shard = (blockIdx.x * (blockDim.x >> 6) + wave_id) & (EPV_SHARDS - 1u);
   // per-wave slab: the pair list, q rows of 64 interleaved records, the flat heavy list
@@ -146,10 +155,27 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     const unsigned long long rmask = __ballot(run);
     const int hi_lane = rmask ? 63 - __clzll((long long)rmask) : 0;
     const uint32_t totH = rmask ? epv_bcast(inclH, hi_lane) : 0u, totP = rmask ? epv_bcast(inclP, hi_lane) : 0u;
-    const uint32_t hbase = inclH - wantH, pbase = inclP - wantP;
+    const uint32_t hbase = inclH - wantH;
+    // The pairs are grouped by level -- leaf branches, then the internal nodes of depth 1, 2, ... --
+    // so that a level's pair pass finds its pairs side by side: within a group by lane, then by node
+    {
+      uint32_t gb = 0u;
+      for (uint32_t g = 0; g < depth; ++g) {
+        const uint32_t cnt = run ? (uint32_t)__popcll(mH & group_mask(g)) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(cnt);
+        s_goff[g * 64u + lane] = (uint16_t)(gb + incl - cnt);
+        if (lane == 0) s_gstart[g] = gb;
+        gb += epv_bcast(incl, 63);
+      }
+      if (lane == 0) s_gstart[depth] = gb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // slot of this lane's heavy pair at `node` in the pair list (and in s_pf / s_pb)
     auto slot_of = [&](uint32_t node) __attribute__((always_inline)) -> uint32_t {
-      return pbase + (uint32_t)__popcll(mH & ((1ull << node) - 1ull));
+      const uint32_t nw = s_tree[node];
+      const uint32_t g = EPV_P3_LEAF(nw) ? 0u : EPV_P3_DEPTH(nw);
+      return (uint32_t)s_goff[g * 64u + lane] + (uint32_t)__popcll(mH & group_mask(g) & ((1ull << node) - 1ull));
     };
 
     P2_MARK(1);
@@ -157,7 +183,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     //         words (the segment counts) share a round trip
     if (run && n_pairs) {
       unsigned long long h = mH;
-      uint32_t hcur = hbase, at = pbase;
+      uint32_t hcur = hbase;
       while (h) {
         uint32_t nd[4], K[4];
 #pragma unroll
@@ -174,7 +200,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
         for (int q = 0; q < 4; ++q) {
           if (!nd[q]) continue;
           const uint32_t leaf_state = (uint32_t)((mM ^ mMp) >> nd[q]) & 1u;
-          plist[at++] = (unsigned long long)lane | ((unsigned long long)nd[q] << 6) | ((unsigned long long)K[q] << 12) |
+          plist[slot_of(nd[q])] = (unsigned long long)lane | ((unsigned long long)nd[q] << 6) | ((unsigned long long)K[q] << 12) |
                         ((unsigned long long)hcur << 32) | ((unsigned long long)leaf_state << 62);
           hcur += K[q];
         }
@@ -266,14 +292,14 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     // level 0 = the leaf branches (q is the observed state), d >= 1 = the internal nodes of depth d
     // (q from the row the nodes' pass has just written).
     auto pair_pass = [&](uint32_t level) __attribute__((always_inline)) {
-      for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
+      const uint32_t pend = s_gstart[level + 1u];
+      for (uint32_t p0 = s_gstart[level]; p0 < pend; p0 += 64u) {
         const uint32_t pidx = p0 + (uint32_t)lane;
-        if (pidx >= totP) continue;
+        if (pidx >= pend) continue;
         const unsigned long long pr = plist[pidx];
         const uint32_t owner = (uint32_t)pr & 63u, node = ((uint32_t)pr >> 6) & 63u, K = ((uint32_t)(pr >> 12)) & 0xfffffu;
         const uint32_t hrec0 = (uint32_t)(pr >> 32) & 0xfffffu;
         const uint32_t nw = s_tree[node];
-        if ((EPV_P3_LEAF(nw) ? 0u : EPV_P3_DEPTH(nw)) != level) continue;
         double q0, q1;
         if (EPV_P3_LEAF(nw)) {
           const uint32_t leaf_state = (uint32_t)(pr >> 62) & 1u;
