@@ -62,6 +62,7 @@ struct epv_ctx {
   bool mh_gpool = false;        // record pool of the propose kernel in global memory (large trees)
   double *d_gpool = nullptr;
   uint64_t gpool_cap = 0;       // doubles allocated
+  uint64_t gpool_need = 0, gpool2_need = 0, gpool3_need = 0;   // what the plans ask for; allocated when a launch first uses the slab
   // second-generation proposal kernel (epv_propose2.h)
   bool use_p2 = true;            // EPV_PROPOSE_V1=1 falls back to the first kernel (A/B runs)
   uint32_t p2_pool = 0, p2_list_cap = 0;   // LDS: doubles per wave; global slab: rows per lane + heavy records
@@ -70,6 +71,8 @@ struct epv_ctx {
   size_t p2_lds = 0;
   double *d_gpool2 = nullptr;
   uint64_t gpool2_cap = 0;
+  double *d_gpool3 = nullptr;
+  uint64_t gpool3_cap = 0;
   double *d_segtab = nullptr;    // [B][4][6] single-segment matrices, refreshed by epv_reset
   // third proposal kernel (epv_propose3.h): large trees, where the record pool does not fit LDS
   int use_p3 = -1;               // -1 = whenever the plan allows it, EPV_PROPOSE_V3=0/1 forces
@@ -183,14 +186,7 @@ int plan_mh(epv_ctx *c) {
   // global slab: `worst` ROWS of 64 interleaved records per wave (a lane can always run)
   const uint64_t pool = worst;
   const uint64_t blocks = (c->S.phase_cap + 63u) / 64u;
-  const uint64_t need = blocks * pool * 128u;
-  if (need > c->gpool_cap) {
-    dfree(c->d_gpool);
-    c->gpool_cap = 0;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMalloc(&c->d_gpool, need * sizeof(double)));
-    c->gpool_cap = need;
-  }
+  c->gpool_need = blocks * pool * 128u;     // (allocated by ensure_slab when a launch takes this kernel)
   c->mh_gpool = true;
   c->pool_entries = (uint32_t)pool;
   c->mh_lds = fixed;
@@ -262,14 +258,7 @@ int plan_p2(epv_ctx *c) {
   const uint64_t rows = worst_rec;
   const uint64_t list_cap = std::max<uint64_t>(worst_heavy, (uint64_t)(64.0 * B * heavy_per_branch * 2.0) + 64u);
   const uint64_t blocks = (c->S.phase_cap + 63u) / 64u;
-  const uint64_t need = blocks * (rows * 128u + list_cap * EPV_HREC);
-  if (need > c->gpool2_cap) {
-    dfree(c->d_gpool2);
-    c->gpool2_cap = 0;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMalloc(&c->d_gpool2, need * sizeof(double)));
-    c->gpool2_cap = need;
-  }
+  c->gpool2_need = blocks * (rows * 128u + list_cap * EPV_HREC);
   c->p2_gpool = true;
   c->p2_pool = (uint32_t)rows;
   c->p2_list_cap = (uint32_t)list_cap;
@@ -347,12 +336,7 @@ int plan_p3(epv_ctx *c) {
   const uint64_t need = waves * ((uint64_t)EPV_P3_PCAP + (uint64_t)qrows * 128u + list_cap * EPV_HREC_SHORT);
   if (need * sizeof(double) > (24ull << 30)) return EPV_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (need > c->gpool2_cap) {
-    dfree(c->d_gpool2);
-    c->gpool2_cap = 0;
-    HIP_TRY(c, hipMalloc(&c->d_gpool2, need * sizeof(double)));
-    c->gpool2_cap = need;
-  }
+  c->gpool3_need = need;
   if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 512u * sizeof(uint32_t)));
   HIP_TRY(c, hipMemcpy(c->d_nodetab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * EPV_SEGTAB_DBL * 8u + (tab.size() + 1u) / 2u * 8u;
@@ -542,6 +526,19 @@ int launch_suffstats(epv_ctx *c, uint64_t slot) {
   return reduce_blocks_to_tot(c, c->d_partial[0], nb, 1u, slot);
 }
 
+// the global-memory slab of a proposal kernel, allocated when a launch first takes that kernel (a
+// context on a large tree plans three kernels but runs one: 5 - 50 GB each at full size)
+int ensure_slab(epv_ctx *c, double **slab, uint64_t *cap, uint64_t need) {
+  if (need <= *cap) return EPV_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  dfree(*slab);
+  *cap = 0;
+  HIP_TRY(c, hipMalloc(slab, need * sizeof(double)));
+  *cap = need;
+  return EPV_OK;
+}
+
 int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
   uint64_t first = 0, last = 0, own_lo = 0, own_hi = 0;
   int prc = phase_range(c, &first, &last);
@@ -608,14 +605,16 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     // large tree: a 16-bit word per (node, lane) in LDS, q rows and heavy records in a slab (epv_propose3.h)
     list_mode = 1u + (c->phase_parity & 1u);
     const unsigned pb = (unsigned)((threads + 255u) / 256u);
+    { const int rc3 = ensure_slab(c, &c->d_gpool3, &c->gpool3_cap, c->gpool3_need); if (rc3) return rc3; }
     hipLaunchKernelGGL(epv_mh_propose3_kernel<false>, dim3(pb), dim3(256), c->p3_lds, c->stream, c->S, (uint32_t)colour,
                        (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->p3_list_cap,
-                       c->p3_qrows, c->p3_nup, c->p3_depth, c->phase_parity & 1u, c->d_counters, c->d_gpool2, c->d_segtab,
+                       c->p3_qrows, c->p3_nup, c->p3_depth, c->phase_parity & 1u, c->d_counters, c->d_gpool3, c->d_segtab,
                        c->d_nodetab);
     ++c->phase_parity;
   } else if (p2) {
     list_mode = 1u + (c->phase_parity & 1u);
     const unsigned pt = 64u * c->p2_waves, pb = (unsigned)((threads + pt - 1u) / pt);
+    if (c->p2_gpool) { const int rc2 = ensure_slab(c, &c->d_gpool2, &c->gpool2_cap, c->gpool2_need); if (rc2) return rc2; }
     auto kern = c->p2_gpool ? (seg_mode ? epv_mh_propose2_kernel<true, true, false> : epv_mh_propose2_kernel<true, false, false>)
                             : (seg_mode ? epv_mh_propose2_kernel<false, true, false> : epv_mh_propose2_kernel<false, false, false>);
     hipLaunchKernelGGL(kern, dim3(pb), dim3(pt), c->p2_lds, c->stream, c->S, (uint32_t)colour, (uint32_t)seed,
@@ -624,6 +623,7 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
                        EpvFused{});
     ++c->phase_parity;
   } else {
+    if (c->mh_gpool) { const int rc1 = ensure_slab(c, &c->d_gpool, &c->gpool_cap, c->gpool_need); if (rc1) return rc1; }
     auto kern = c->mh_gpool ? (refq ? epv_mh_propose_kernel<true, true> : epv_mh_propose_kernel<true, false>)
                             : (refq ? epv_mh_propose_kernel<false, true> : epv_mh_propose_kernel<false, false>);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(c->mh_threads), c->mh_lds, c->stream, c->S,
@@ -783,7 +783,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_sweep_tot); dfree(c->d_statscale); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_segtab); dfree(c->d_nodetab);
+  dfree(c->d_counters); dfree(c->d_sweep_tot); dfree(c->d_statscale); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_gpool3); dfree(c->d_segtab); dfree(c->d_nodetab);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   if (c->h_cnt_snap) (void)hipHostFree(c->h_cnt_snap);
   for (hipEvent_t &e : c->ev_copy) if (e) { (void)hipEventDestroy(e); e = nullptr; }

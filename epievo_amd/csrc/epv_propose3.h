@@ -120,14 +120,18 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
   const double *s_blen = s_const + 20;
 
   const uint64_t Bn = (uint64_t)B * n, Cn = (uint64_t)S.C * n;
-  const uint64_t mbaseL = (selL ? Bn : 0ull) + (site - 1), mbaseR = (selR ? Bn : 0ull) + (site + 1);
-  const uint64_t mbaseM = (selM ? Bn : 0ull) + site;
-  const uint64_t jbaseL = (selL ? Bn * S.C : 0ull) + (site - 1), jbaseR = (selR ? Bn * S.C : 0ull) + (site + 1);
+  // (the plane offsets of the three columns are recomputed from the site and the buffer bits where they
+  // are needed: ten registers that would otherwise live through the whole kernel)
+  const uint32_t selbits = selL | (selM << 1) | (selR << 2);
+  const uint32_t tid32 = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t site_lane0 = s0 + 3u * (uint64_t)(tid32 - (uint32_t)lane);
   // ---- 0. the meta words of the three columns, in batches of independent loads, condensed to six
   //         masks (bit `node` = the branch above the node)
   unsigned long long mR = 0ull, mL = 0ull, mM = 0ull, mMp = 0ull, mMj = 0ull, mH = 0ull;
   uint32_t heavy = 0, n_pairs = 0;
   if (valid) {
+    const uint64_t mbaseL = (selL ? Bn : 0ull) + (site - 1), mbaseR = (selR ? Bn : 0ull) + (site + 1);
+    const uint64_t mbaseM = (selM ? Bn : 0ull) + site;
 #pragma unroll 6
     for (uint32_t b = 0; b < B; ++b) {
       const uint32_t wL = S.meta[mbaseL + (uint64_t)b * n];
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     // ---- 1. the heavy (lane, node) pairs, up to four per step so that the re-reads of their meta
     //         words (the segment counts) share a round trip
     if (run && n_pairs) {
+      const uint64_t mbaseL = ((selbits & 1u) ? Bn : 0ull) + (site - 1), mbaseR = ((selbits & 4u) ? Bn : 0ull) + (site + 1);
       unsigned long long h = mH;
       uint32_t hcur = hbase;
       while (h) {
@@ -226,10 +231,10 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         const uint32_t owner = (uint32_t)pr[q] & 63u, b = ((((uint32_t)pr[q] >> 6) & 63u) - 1u) & 63u;
-        const uint64_t jl = (uint64_t)__shfl((uint32_t)jbaseL, (int)owner) | ((uint64_t)__shfl((uint32_t)(jbaseL >> 32), (int)owner) << 32);
-        const uint64_t jr = (uint64_t)__shfl((uint32_t)jbaseR, (int)owner) | ((uint64_t)__shfl((uint32_t)(jbaseR >> 32), (int)owner) << 32);
-        const uint64_t ml = (uint64_t)__shfl((uint32_t)mbaseL, (int)owner) | ((uint64_t)__shfl((uint32_t)(mbaseL >> 32), (int)owner) << 32);
-        const uint64_t mr = (uint64_t)__shfl((uint32_t)mbaseR, (int)owner) | ((uint64_t)__shfl((uint32_t)(mbaseR >> 32), (int)owner) << 32);
+        const uint32_t osel = (uint32_t)__shfl((int)selbits, (int)owner);
+        const uint64_t osite = site_lane0 + 3u * (uint64_t)owner;
+        const uint64_t ml = ((osel & 1u) ? Bn : 0ull) + (osite - 1), mr = ((osel & 4u) ? Bn : 0ull) + (osite + 1);
+        const uint64_t jl = ((osel & 1u) ? Bn * S.C : 0ull) + (osite - 1), jr = ((osel & 4u) ? Bn * S.C : 0ull) + (osite + 1);
         cL[q] = act[q] ? (uint32_t)S.meta[ml + (uint64_t)b * n] : 0u;
         cR[q] = act[q] ? (uint32_t)S.meta[mr + (uint64_t)b * n] : 0u;
         Lj[q] = S.jumps + jl + (uint64_t)b * Cn;
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
       for (uint32_t node = 1u; node < N; ++node) {
         const uint32_t par = EPV_P3_PARENT(s_tree[node]);
         const uint32_t st = (par == 0u) ? root_state : (uint32_t)(mEnd >> par) & 1u;
-        S.meta[(selM ? 0ull : Bn) + (uint64_t)(node - 1u) * n + site] = (epv_meta_t)(st << EPV_INIT_SHIFT);
+        S.meta[((selbits & 2u) ? 0ull : Bn) + (uint64_t)(node - 1u) * n + site] = (epv_meta_t)(st << EPV_INIT_SHIFT);
       }
       S.prop_flag[tid] = 0u;
     }

@@ -24,7 +24,8 @@ import pmc_load  # noqa: E402
 
 CLOCK_GHZ = 2.4      # MI355X peak engine clock
 SIMDS = 1024
-MH = ("epv_mh_propose_kernel", "epv_mh_propose2_kernel", "epv_mh_jumps_kernel", "epv_mh_accept_kernel")
+MH = ("epv_mh_propose_kernel", "epv_mh_propose2_kernel", "epv_mh_propose3_kernel", "epv_mh_jumps_kernel",
+      "epv_mh_accept_kernel", "epv_mh_accept3_kernel")
 
 
 def short(name):
@@ -69,7 +70,8 @@ def main():
     data = json.load(open(ij)) if os.path.exists(ij) else {}
     mh = [k for k in sorted(acc) if k in MH]
     # EPV_PHASE_* of include/epievo_mi355x.h, from the kernels that ran
-    mode = 3 if mh == ["epv_mh_propose2_kernel"] else 0 if "epv_mh_propose_kernel" in mh else \
+    mode = 3 if mh == ["epv_mh_propose2_kernel"] else 4 if "epv_mh_propose3_kernel" in mh else \
+        0 if "epv_mh_propose_kernel" in mh else \
         2 if "epv_seg_search_kernel" in acc else 1
     data[config] = {"round": tag, "kernels": "+".join(mh), "phase_mode": mode,
                     "valu_wave_insts_per_launch": total, "cycles_per_inst": 4, "simds": SIMDS,
