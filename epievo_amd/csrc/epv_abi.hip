@@ -333,14 +333,14 @@ int plan_p3(epv_ctx *c) {
   const uint64_t list_cap = min_list ? worst_heavy : std::max<uint64_t>(worst_heavy, (uint64_t)(64.0 * B * heavy_per_branch * 1.5) + 64u);
   if (list_cap >= (1ull << 20)) return EPV_OK;             // the pair word's record field
   const uint64_t waves = ((c->S.phase_cap + 255u) / 256u) * 4u;
-  const uint64_t need = waves * ((uint64_t)EPV_P3_PCAP + (uint64_t)qrows * 128u + list_cap * EPV_HREC_SHORT);
+  const uint64_t need = waves * ((uint64_t)qrows * 128u + list_cap * EPV_HREC_SHORT);
   if (need * sizeof(double) > (24ull << 30)) return EPV_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   c->gpool3_need = need;
   if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 512u * sizeof(uint32_t)));
   HIP_TRY(c, hipMemcpy(c->d_nodetab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * EPV_SEGTAB_DBL * 8u + (tab.size() + 1u) / 2u * 8u;
-  const size_t per_wave = ((size_t)EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u + (max_depth * 64u * 2u + 7u) / 8u + (max_depth + 3u) / 2u) * 8u;   // pair results, group offsets
+  const size_t per_wave = ((size_t)EPV_P3_PCAP * 3u + EPV_P3_PCAP / 8u + (max_depth * 64u * 2u + 7u) / 8u + (max_depth + 3u) / 2u) * 8u;   // pair list, pair results, group offsets
   c->p3_lds = shared + 4u * per_wave;
   c->p3_list_cap = (uint32_t)list_cap;
   c->p3_qrows = qrows;

@@ -29,8 +29,8 @@
 //     the uniforms of a segment being fixed -- the chain of end states for BOTH start states, leaving
 //     p.front (16 B) and four result bits in LDS for the lanes that own the sites.  The sequential
 //     parts never iterate over segments.
-// LDS per wave: 4.3 KB (pair results) instead of 19.5 (second kernel); global traffic per wave: the
-// 14 q rows and the heavy records.
+// LDS per wave: 6.9 KB (pair list and results) instead of 19.5 (second kernel); global traffic per
+// wave: the 14 q rows and the heavy records.
 //
 // Preconditions (plan_p3, epv_abi.hip): N <= 64, every node but the root has at most two children.
 
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
   const uint32_t tree_dbl = (tree_words + 1u) / 2u;
   // per wave: p.front and result bits of the pairs, each lane's first slot per group, the groups' starts
   const uint32_t goff_dbl = (depth * 64u * 2u + 7u) / 8u, gstart_dbl = (depth + 2u + 1u) / 2u;
-  const uint32_t wave_dbl = EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u + goff_dbl + gstart_dbl;
+  const uint32_t wave_dbl = EPV_P3_PCAP * 3u + EPV_P3_PCAP / 8u + goff_dbl + gstart_dbl;
   const uint32_t wave_id = threadIdx.x >> 6;
   double *s_const = s_mem;
   double *s_tab = s_mem + const_dbl;
@@ -91,16 +91,16 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
   uint8_t *s_pb = reinterpret_cast<uint8_t *>(s_pf + EPV_P3_PCAP * 2u);
   uint16_t *s_goff = reinterpret_cast<uint16_t *>(s_pf + EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u);
   uint32_t *s_gstart = reinterpret_cast<uint32_t *>(s_pf + EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u + goff_dbl);
+  // the pair list (read by five passes: in LDS, a round trip less in each)
+  unsigned long long *plist = reinterpret_cast<unsigned long long *>(s_pf + EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u + goff_dbl + gstart_dbl);
   auto group_mask = [&](uint32_t g) __attribute__((always_inline)) -> unsigned long long {
     return (unsigned long long)s_gmask[2u * g] | ((unsigned long long)s_gmask[2u * g + 1u] << 32);
   };
   const int lane = epv_lane();
   const uint32_t my_shard = (blockIdx.x * (blockDim.x >> 6) + wave_id) & (EPV_SHARDS - 1u);
-  // per-wave slab: the pair list, q rows of 64 interleaved records, the flat heavy list
-  double *slab = gpool + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_id) *
-                             ((size_t)EPV_P3_PCAP + (size_t)n_qrows * 128u + (size_t)list_cap * HREC);
-  unsigned long long *plist = reinterpret_cast<unsigned long long *>(slab);
-  double *qrows = slab + EPV_P3_PCAP;
+  // per-wave slab: q rows of 64 interleaved records, the flat heavy list
+  double *qrows = gpool + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_id) *
+                              ((size_t)n_qrows * 128u + (size_t)list_cap * HREC);
   double *list = qrows + (size_t)n_qrows * 128u;
   const uint64_t gfirst = S.g0 + first;
   const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
@@ -274,10 +274,8 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     P2_MARK(2);
     // ---- 3. evaluate them densely, one segment per lane: matrices, no-jump bounds, the segment's
     //         Philox block (none of which depends on the recursion state)
-    for (uint32_t i = (uint32_t)lane; i < totH; i += 64u) {
-      double *rec = list + (size_t)i * HREC;
-      const double len = rec[LEN_AT];
-      const uint64_t info = epv_d2u(rec[INFO_AT]);
+    //         (two chunks of segments per step: their loads share a round trip)
+    auto eval_segment = [&](double *rec, double len, uint64_t info) __attribute__((always_inline)) {
       const uint32_t trip0 = (uint32_t)info & 7u, owner = (uint32_t)(info >> 3) & 63u;
       const uint32_t node = (uint32_t)(info >> 9) & 4095u, k = (uint32_t)(info >> 21);
       double m[6];
@@ -287,6 +285,16 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
       for (int q = 0; q < 6; ++q) rec[q] = m[q];
       rec[6] = blk.d0;
       rec[7] = blk.d1;
+    };
+    for (uint32_t i = (uint32_t)lane; i < totH; i += 128u) {
+      double *recA = list + (size_t)i * HREC, *recB = recA + 64u * HREC;
+      const bool hasB = i + 64u < totH;
+      const double lenA = recA[LEN_AT];
+      const uint64_t infoA = epv_d2u(recA[INFO_AT]);
+      const double lenB = hasB ? recB[LEN_AT] : 0.0;
+      const uint64_t infoB = hasB ? epv_d2u(recB[INFO_AT]) : 0ull;
+      eval_segment(recA, lenA, infoA);
+      if (hasB) eval_segment(recB, lenB, infoB);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
