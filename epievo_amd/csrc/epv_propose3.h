@@ -420,9 +420,9 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     // ---- 4. pruning (SingleSiteSampler.cpp:116-157), deepest level first.  A level: q of its internal
     //         nodes from their children's p.front -- a heavy child's from its pair lane, any other
     //         recomputed from the child's q and the matrix table -- then the level's heavy pairs.
-    pair_pass(0u);
-    for (uint32_t d = depth; d-- > 1u;) {
-      if (run) {
+    //         (one loop, so that the pair pass -- the largest piece of code here -- is instantiated once)
+    for (uint32_t d = depth; d >= 1u; --d) {
+      if (run && d < depth) {
         const uint32_t i0 = s_upstart[d + 1u], i1 = s_upstart[d];     // (deepest first: level d + 1 precedes level d)
         for (uint32_t ib = i0; ib < i1; ib += 4u) {
           // the q rows of up to eight internal children in one batch
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      pair_pass(d);
+      pair_pass(d == depth ? 0u : d);
     }
     P2_MARK(4);
 
