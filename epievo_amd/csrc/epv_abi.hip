@@ -78,6 +78,8 @@ struct epv_ctx {
   int use_p3 = -1;               // -1 = whenever the plan allows it, EPV_PROPOSE_V3=0/1 forces
   bool p3 = false;               // decided by plan_p3 for the uploaded tree and paths
   uint32_t p3_list_cap = 0, p3_qrows = 0, p3_nup = 0, p3_depth = 0;
+  uint32_t p3_slots = 0;         // slabs per XCD handed out to resident blocks (0 = a slab per block of the launch)
+  uint32_t *d_slabflags = nullptr;
   size_t p3_lds = 0;
   uint32_t *d_nodetab = nullptr; // node words and level lists of epv_mh_propose3_kernel (EPV_P3_*)
   uint32_t phase_parity = 0;     // accept lists are double-buffered by phase parity
@@ -332,12 +334,22 @@ int plan_p3(epv_ctx *c) {
   static const bool min_list = std::getenv("EPV_P3_MIN_LIST") != nullptr;
   const uint64_t list_cap = min_list ? worst_heavy : std::max<uint64_t>(worst_heavy, (uint64_t)(64.0 * B * heavy_per_branch * 1.5) + 64u);
   if (list_cap >= (1ull << 20)) return EPV_OK;             // the pair word's record field
-  const uint64_t waves = ((c->S.phase_cap + 255u) / 256u) * 4u;
+  // a pool of slabs per XCD, claimed by resident blocks (EPV_P3_SLAB_POOL=0: one per block of the launch):
+  // 4 blocks of this kernel fit a CU (LDS) and an XCD of the MI355X has 32 CUs: 128 resident blocks at most,
+  // 160 slabs per XCD.  Used when the launch has more blocks than the pool has slabs (EPV_P3_SLAB_POOL=2: always)
+  static const int pool_env = std::getenv("EPV_P3_SLAB_POOL") ? std::atoi(std::getenv("EPV_P3_SLAB_POOL")) : 1;
+  const uint64_t launch_waves = ((c->S.phase_cap + 255u) / 256u) * 4u;
+  c->p3_slots = (pool_env == 2 || (pool_env && launch_waves > 8u * 160u * 4u)) ? 160u : 0u;
+  const uint64_t waves = c->p3_slots ? 8ull * c->p3_slots * 4u : launch_waves;
   const uint64_t need = waves * ((uint64_t)qrows * 128u + list_cap * EPV_HREC_SHORT);
   if (need * sizeof(double) > (24ull << 30)) return EPV_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   c->gpool3_need = need;
   if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 512u * sizeof(uint32_t)));
+  if (!c->d_slabflags) {
+    HIP_TRY(c, hipMalloc(&c->d_slabflags, 8u * 256u * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemset(c->d_slabflags, 0, 8u * 256u * sizeof(uint32_t)));
+  }
   HIP_TRY(c, hipMemcpy(c->d_nodetab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * EPV_SEGTAB_DBL * 8u + (tab.size() + 1u) / 2u * 8u;
   const size_t per_wave = ((size_t)EPV_P3_PCAP * 3u + EPV_P3_PCAP / 8u + (max_depth * 64u * 2u + 7u) / 8u + (max_depth + 3u) / 2u) * 8u;   // pair list, pair results, group offsets
@@ -609,7 +621,7 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     hipLaunchKernelGGL(epv_mh_propose3_kernel<false>, dim3(pb), dim3(256), c->p3_lds, c->stream, c->S, (uint32_t)colour,
                        (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->p3_list_cap,
                        c->p3_qrows, c->p3_nup, c->p3_depth, c->phase_parity & 1u, c->d_counters, c->d_gpool3, c->d_segtab,
-                       c->d_nodetab);
+                       c->d_nodetab, c->d_slabflags, c->p3_slots);
     ++c->phase_parity;
   } else if (p2) {
     list_mode = 1u + (c->phase_parity & 1u);
@@ -755,7 +767,7 @@ EPV_API epv_ctx *epv_create(int device_id) {
   }
   // the MH kernel asks for more dynamic LDS than the 64 KiB default
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose3_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);   // (it has static LDS too)
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, true, false>),
@@ -783,7 +795,7 @@ EPV_API void epv_destroy(epv_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_paths(c);
   dfree(c->d_model); dfree(c->d_parent); dfree(c->d_subtree); dfree(c->d_blen);
-  dfree(c->d_counters); dfree(c->d_sweep_tot); dfree(c->d_statscale); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_gpool3); dfree(c->d_segtab); dfree(c->d_nodetab);
+  dfree(c->d_counters); dfree(c->d_sweep_tot); dfree(c->d_statscale); dfree(c->d_scale); dfree(c->d_indep); dfree(c->d_gpool); dfree(c->d_stage); dfree(c->d_lvl); dfree(c->d_rows); dfree(c->d_gpool2); dfree(c->d_gpool3); dfree(c->d_segtab); dfree(c->d_nodetab); dfree(c->d_slabflags);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   if (c->h_cnt_snap) (void)hipHostFree(c->h_cnt_snap);
   for (hipEvent_t &e : c->ev_copy) if (e) { (void)hipEventDestroy(e); e = nullptr; }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first,
     uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t list_cap, uint32_t n_qrows, uint32_t n_up,
     uint32_t depth, uint32_t parity, unsigned long long *counters, double *gpool, const double *segtab,
-    const uint32_t *nodetab) {
+    const uint32_t *nodetab, uint32_t *slab_flags, uint32_t slab_slots) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   constexpr uint32_t HREC = EPV_HREC_SHORT, LEN_AT = HREC - 2u, INFO_AT = HREC - 1u;
 #ifdef EPV_P2_PROFILE
@@ -98,9 +98,30 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
   };
   const int lane = epv_lane();
   const uint32_t my_shard = (blockIdx.x * (blockDim.x >> 6) + wave_id) & (EPV_SHARDS - 1u);
-  // per-wave slab: q rows of 64 interleaved records, the flat heavy list
-  double *qrows = gpool + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_id) *
-                              ((size_t)n_qrows * 128u + (size_t)list_cap * HREC);
+  // per-wave slab: q rows of 64 interleaved records, the flat heavy list.  slab_slots != 0: the block
+  // takes a slab from a pool of `slab_slots` per XCD (a flag each, claimed with a compare-and-swap)
+  // instead of owning one by its index -- a slab is scratch for the lifetime of a wave, and with one
+  // per RESIDENT block the slabs' lines are reused while they are still in the XCD's L2 / the
+  // memory-side cache instead of streaming 80 KB per wave through HBM (and the allocation shrinks
+  // from phase_cap / 64 slabs to 8 x slab_slots x 4).  The pool is per XCD because the L2s of
+  // different XCDs are not coherent with each other: a slab must never change XCD.
+  __shared__ uint32_t s_slab;
+  if (slab_slots) {
+    if (threadIdx.x == 0) {
+      const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;     // HW_REG_XCC_ID[3:0]
+      uint32_t *pool = slab_flags + xcc * slab_slots;
+      uint32_t i = (blockIdx.x >> 3) % slab_slots, tries = 0;
+      while (atomicCAS(&pool[i], 0u, 1u) != 0u) {
+        i = i + 1u == slab_slots ? 0u : i + 1u;
+        // (the pool holds more slabs than an XCD can have resident blocks of this kernel: a free one always exists)
+        if (++tries > (1u << 24)) __builtin_trap();
+      }
+      s_slab = xcc * slab_slots + i;
+    }
+    __syncthreads();
+  }
+  const size_t slab_index = slab_slots ? (size_t)s_slab * 4u + wave_id : (size_t)blockIdx.x * (blockDim.x >> 6) + wave_id;
+  double *qrows = gpool + slab_index * ((size_t)n_qrows * 128u + (size_t)list_cap * HREC);
   double *list = qrows + (size_t)n_qrows * 128u;
   const uint64_t gfirst = S.g0 + first;
   const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
@@ -636,6 +657,12 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     __builtin_amdgcn_wave_barrier();     // (a later round reuses the pair list, the rows and the records)
     pending = pending && !run;
     P2_MARK(7);
+  }
+  if (slab_slots) {
+    // every store of this block into the slab has reached the L2 before the flag lets the next block in
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicExch(&slab_flags[s_slab], 0u);
   }
 #ifdef EPV_P2_PROFILE
   if (epv_lane() == 0) {
