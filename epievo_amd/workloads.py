@@ -47,13 +47,20 @@ def tree_nwk():
 
 def config(name):
     """the tree of the named configuration: tree (4-leaf test/tree.nwk), pair (one branch,
-    T = 1), bal16 (16-leaf balanced), or one of EXTRA_TREES"""
+    T = 1), bal16 / bal32 (balanced), cat20 (caterpillar), or one of EXTRA_TREES"""
     if name == "tree":
         return tree_nwk()
     if name == "pair":
         return host.Tree.single_branch(1.0)
     if name == "bal16":
         return host.Tree.balanced(16, 0.05)
+    if name == "bal32":          # 63 nodes: the widest tree the large-tree kernels take (node masks are one word)
+        return host.Tree.balanced(32, 0.03)
+    if name == "cat20":          # a caterpillar of 20 leaves: 39 nodes, 19 levels
+        text = "(L0:0.05,L1:0.07)I0:0.03"
+        for i in range(2, 20):
+            text = "(%s,L%d:%.3f)I%d:%.3f" % (text, i, 0.04 + 0.01 * (i % 5), i - 1, 0.02 + 0.005 * (i % 3))
+        return host.Tree.read(_tmp("cat20.nwk", text.rsplit(":", 1)[0] + ":0.0;\n"))
     if name in EXTRA_TREES:
         return host.Tree.read(_tmp(name + ".nwk", EXTRA_TREES[name]))
     raise KeyError(name)
