@@ -354,6 +354,7 @@ int plan_p3(epv_ctx *c) {
   const size_t shared = const_lds_bytes(N) + (size_t)B * 4u * EPV_SEGTAB_DBL * 8u + (tab.size() + 1u) / 2u * 8u;
   const size_t per_wave = ((size_t)EPV_P3_PCAP * 3u + EPV_P3_PCAP / 8u + (max_depth * 64u * 2u + 7u) / 8u + (max_depth + 3u) / 2u) * 8u;   // pair list, pair results, group offsets
   c->p3_lds = shared + 4u * per_wave;
+  if (c->p3_lds > 120u * 1024u) return EPV_OK;      // (a very deep tree's group offsets: keep the first kernels)
   c->p3_list_cap = (uint32_t)list_cap;
   c->p3_qrows = qrows;
   c->p3_nup = n_up;
