@@ -691,11 +691,18 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
       const unsigned ax3 = (unsigned)std::max<uint64_t>(1u, (per_shard + 4u * EPV_ACC3_SITES - 1u) / (4u * EPV_ACC3_SITES));
       hipLaunchKernelGGL(epv_mh_accept3_kernel, dim3(ax3, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N), c->stream,
                          c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo,
-                         own_hi, c->d_counters, list_mode);
+                         own_hi, c->d_counters, list_mode, (uint64_t)0);
     } else
     hipLaunchKernelGGL(epv_mh_accept_kernel, dim3(ax, EPV_SHARDS), dim3(256), acc_lds, c->stream,
                        c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo,
                        own_hi, c->d_counters, list_mode, meta_cache);
+  } else if (static const int acc_v3b = std::getenv("EPV_ACCEPT_V3") ? std::atoi(std::getenv("EPV_ACCEPT_V3")) : -1;
+             acc_v3b >= 0 ? acc_v3b != 0 : !meta_cache) {
+    // every site of the colour (reference proposal arithmetic on a large tree), a lane per (site, triple)
+    const unsigned ax3 = (unsigned)std::max<uint64_t>(1u, (threads + 4u * EPV_ACC3_SITES - 1u) / (4u * EPV_ACC3_SITES));
+    hipLaunchKernelGGL(epv_mh_accept3_kernel, dim3(ax3, 1), dim3(256), const_lds_bytes(c->S.N), c->stream,
+                       c->S, (uint32_t)colour, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo,
+                       own_hi, c->d_counters, 0u, (uint64_t)threads);
   } else {
     hipLaunchKernelGGL(epv_mh_accept_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256),
                        acc_lds, c->stream, c->S, (uint32_t)colour, (uint32_t)seed,

@@ -1,7 +1,7 @@
 #ifndef EPV_ACCEPT3_H
 #define EPV_ACCEPT3_H
-// epv_accept3.h -- acceptance of a colour phase's listed proposals on LARGE trees (included by
-// epv_kernels.h).  Same decisions as epv_mh_accept_kernel in list mode (log_accept_rate
+// epv_accept3.h -- acceptance of a colour phase's proposals on LARGE trees (included by
+// epv_kernels.h).  Same decisions as epv_mh_accept_kernel, list mode or not (log_accept_rate
 // SingleSiteSampler.cpp:396-433, Metropolis_Hastings_site :510-533), organised around what bounds
 // that kernel on the 16-leaf tree: with 30 branches the meta words of a site's five columns do not
 // fit its LDS cache, so a lane walks three triples x 30 branches with a dependent global round trip
@@ -104,7 +104,7 @@ __device__ __forceinline__ double triple_llh_grouped(const EpvDev &S, const doub
 
 __global__ __launch_bounds__(256, EPV_ACC3_MINBLOCKS) void epv_mh_accept3_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first, uint64_t last,
-    uint64_t own_first, uint64_t own_last, unsigned long long *counters, uint32_t list_mode) {
+    uint64_t own_first, uint64_t own_last, unsigned long long *counters, uint32_t list_mode, uint64_t n_all) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   __shared__ double s_accd[8 * 256];
   __shared__ uint32_t s_accj[8 * 256];
@@ -117,13 +117,16 @@ __global__ __launch_bounds__(256, EPV_ACC3_MINBLOCKS) void epv_mh_accept3_kernel
   const uint64_t gfirst = S.g0 + first;
   const uint64_t s0 = first + ((colour + 3u - (uint32_t)(gfirst % 3u)) % 3u);
   const uint32_t shard_row = blockIdx.y;
-  const unsigned long long n_list = counters[EPV_CNT_IDX(list_mode == 2u ? EPV_CNT_ALIST1 : EPV_CNT_ALIST0, shard_row)];
+  // list_mode 1 / 2: the sites the proposal kernel listed (parity list_mode - 1), one shard of the list per
+  // grid row; 0: every site of the colour (the first proposal kernel lists nothing), one grid row
+  const unsigned long long n_list = list_mode ? counters[EPV_CNT_IDX(list_mode == 2u ? EPV_CNT_ALIST1 : EPV_CNT_ALIST0, shard_row)]
+                                              : (unsigned long long)n_all;
   const uint32_t sidx = (uint32_t)lane / 3u, w = (uint32_t)lane - 3u * sidx;
   const uint64_t per_block = 4ull * EPV_ACC3_SITES;
   for (uint64_t base = (uint64_t)blockIdx.x * per_block; base < n_list; base += (uint64_t)gridDim.x * per_block) {
     const uint64_t li = base + (uint64_t)wave * EPV_ACC3_SITES + sidx;
     bool have = lane < 63 && li < n_list;
-    const uint64_t tid = have ? S.alist[(uint64_t)shard_row * S.alist_cap + li] : 0u;
+    const uint64_t tid = !have ? 0u : list_mode ? (uint64_t)S.alist[(uint64_t)shard_row * S.alist_cap + li] : li;
     const uint64_t site = s0 + 3u * tid;
     have = have && site <= last;
     double v = 0.0, llh_l = 0.0, llh_m = 0.0, llh_r = 0.0, llr = 0.0;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256, EPV_ACC3_MINBLOCKS) void epv_mh_accept3_kernel
         (packed & 0xffffffffull) + (packed >> 32) + (packed2 & 0xffffffffull) + (packed2 >> 32);
     counters[EPV_CNT_IDX(EPV_CNT_TASKS, threadIdx.x)] = 0ull;
     counters[EPV_CNT_IDX(EPV_CNT_TASKS2, threadIdx.x)] = 0ull;
-    counters[EPV_CNT_IDX(list_mode == 2u ? EPV_CNT_ALIST0 : EPV_CNT_ALIST1, threadIdx.x)] = 0ull;
+    if (list_mode) counters[EPV_CNT_IDX(list_mode == 2u ? EPV_CNT_ALIST0 : EPV_CNT_ALIST1, threadIdx.x)] = 0ull;
     counters[EPV_CNT_IDX(EPV_CNT_COOP, threadIdx.x)] += counters[EPV_CNT_IDX(EPV_CNT_SEG, threadIdx.x)] >> 32;
     counters[EPV_CNT_IDX(EPV_CNT_SEG, threadIdx.x)] = 0ull;
   }
