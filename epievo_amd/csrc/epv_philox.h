@@ -58,8 +58,17 @@ __device__ __forceinline__ epv_block2 epv_keyed_block(uint32_t seed_lo, uint32_t
     const uint32_t hi1 = __umulhi(EPV_PHILOX_M1, c2);
     const uint32_t lo1 = EPV_PHILOX_M1 * c2;
 #endif
+#if !defined(EPV_PHILOX_XOR2)
+    // a ^ b ^ key in ONE instruction: gfx950's three-input boolean op with the XOR3 truth table (0x96);
+    // the compiler emits two v_xor_b32 (40 instead of 20 per block).  The key is wave-uniform (kernel
+    // arguments plus round constants), hence the scalar operand.
+    uint32_t n0, n2;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"(hi1), "v"(c1), "s"(k0));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"(hi0), "v"(c3), "s"(k1));
+#else
     const uint32_t n0 = hi1 ^ c1 ^ k0;
     const uint32_t n2 = hi0 ^ c3 ^ k1;
+#endif
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += EPV_PHILOX_W0;
     k1 += EPV_PHILOX_W1;
