@@ -469,8 +469,8 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
 #pragma unroll 1
           for (uint32_t j = 0; j < 4u; ++j) {
             if (ib + j >= i1) break;
-            const uint32_t P = s_up[ib + j];
-            const uint32_t nw = s_tree[P];
+            const uint32_t P = __builtin_amdgcn_readfirstlane(s_up[ib + j]);
+            const uint32_t nw = __builtin_amdgcn_readfirstlane(s_tree[P]);
             double a0 = 1.0, a1 = 1.0;
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
@@ -508,6 +508,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     // ---- 5. downward sampling of the segment END STATES (:180-255), level by level from the root;
     //         the jump times are drawn by epv_mh_jumps_kernel for the dirty branches only
     unsigned long long mEnd = 0ull, dirty = 0ull, multi = 0ull, deep = 0ull;
+    const uint64_t pcW = (uint64_t)S.phase_cap * S.W, tidW = tid * S.W;
     bool ident = true;
     if (run) {
       for (uint32_t d = 1u; d <= depth; ++d) {
@@ -530,8 +531,9 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
 #pragma unroll 1
           for (uint32_t j = 0; j < 4u; ++j) {
             if (ib + j >= i1) break;
-            const uint32_t node = s_dn[ib + j], b = node - 1u;
-            const uint32_t nw = s_tree[node];
+            // (wave-uniform by construction: say so, and what follows from them is scalar work)
+            const uint32_t node = __builtin_amdgcn_readfirstlane(s_dn[ib + j]), b = node - 1u;
+            const uint32_t nw = __builtin_amdgcn_readfirstlane(s_tree[node]);
             const uint32_t par = EPV_P3_PARENT(nw);
             const uint32_t start_state = (par == 0u) ? root_state : (uint32_t)(mEnd >> par) & 1u;
             uint32_t prev;
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
               const double p0 = PT0 * q0 / (start_state ? pk1 : pk0);
               prev = (blk.d0 > p0) ? 1u : 0u;
               clean = (prev == start_state) && (1.0 - blk.d1 < nb);
-              if (!clean) S.prop_states[((uint64_t)b * S.phase_cap + tid) * S.W] = (unsigned long long)prev;
+              if (!clean) S.prop_states[(uint64_t)b * pcW + tidW] = (unsigned long long)prev;
             } else {
               const uint32_t r = s_pb[slot_of(node)];
               prev = (r >> (start_state ? 2u : 0u)) & 1u;
