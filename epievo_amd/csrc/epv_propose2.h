@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
         }
         regA[node * 64u + lane] = off;
         if (K == 1u) {
-          const double *t = s_tab + (size_t)(b * 4u + 2u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT)) * EPV_SEGTAB_DBL;
+          const double *t = s_tab + (b * 4u + 2u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT)) * EPV_SEGTAB_DBL;   // (32-bit index: an LDS address)
           const double P00 = t[0], P11 = t[1];
           const double P01 = 1.0 - P00, P10 = 1.0 - P11;
           double *rec = my + (size_t)off * RS;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, EPV_PROPOSE2_WAVES) void epv_mh_propose2_kerne
           }
           double PT0, nb, u_end, u_first;
           if (K == 1u) {
-            const double *t = s_tab + (size_t)(b * 4u + 2u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT)) * EPV_SEGTAB_DBL;
+            const double *t = s_tab + (b * 4u + 2u * (mL >> EPV_INIT_SHIFT) + (mR >> EPV_INIT_SHIFT)) * EPV_SEGTAB_DBL;   // (32-bit index: an LDS address)
             PT0 = prev ? t[3] : t[2];
             nb = prev ? t[5] : t[4];
             const epv_block2 blk = epv_keyed_block(seed_lo, seed_hi, gsite, sweep, node, 0u, 0u, 0u);

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
                 double q1 = j == 0u ? cq[0][w][1] : j == 1u ? cq[1][w][1] : j == 2u ? cq[2][w][1] : cq[3][w][1];
                 if (EPV_P3_LEAF(s_tree[c])) leaf_q(c, q0, q1);
                 const uint32_t ctx = (uint32_t)(((mL >> c) & 1ull) << 1) | (uint32_t)((mR >> c) & 1ull);
-                const double *t = s_tab + (size_t)((c - 1u) * 4u + ctx) * EPV_SEGTAB_DBL;
+                const double *t = s_tab + ((c - 1u) * 4u + ctx) * EPV_SEGTAB_DBL;     // (32-bit index: an LDS address)
                 const double P00 = t[0], P11 = t[1];
                 const double P01 = 1.0 - P00, P10 = 1.0 - P11;
                 f0 = P00 * q0 + P01 * q1;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
               double q1 = j == 0u ? cq[0][1] : j == 1u ? cq[1][1] : j == 2u ? cq[2][1] : cq[3][1];
               if (EPV_P3_LEAF(nw)) leaf_q(node, q0, q1);
               const uint32_t ctx = (uint32_t)(((mL >> node) & 1ull) << 1) | (uint32_t)((mR >> node) & 1ull);
-              const double *t = s_tab + (size_t)(b * 4u + ctx) * EPV_SEGTAB_DBL;
+              const double *t = s_tab + (b * 4u + ctx) * EPV_SEGTAB_DBL;
               const double P00 = t[0], P11 = t[1];
               const double P01 = 1.0 - P00, P10 = 1.0 - P11;
               const double pk0 = P00 * q0 + P01 * q1;     // p.front, as pruning computed it
