@@ -747,7 +747,7 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
 #endif
 
 #ifndef EPV_JUMPS_WAVES
-#define EPV_JUMPS_WAVES 2   /* waves per SIMD the register allocation aims for: 3 (<= 168 VGPRs) spills 26 registers, 2 is as fast (tools/ab_bench.py) */
+#define EPV_JUMPS_WAVES 3   /* waves per SIMD the register allocation aims for: 3 = 168 VGPRs, no scratch since the Philox XOR3 (round 2: 26 registers spilled, 2 was as fast); 16-leaf tree -5..-8 % per phase, tree.nwk n = 3e6 -5 % */
 #endif
 __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
                                                            uint32_t seed_hi, uint32_t sweep,
