@@ -72,6 +72,12 @@ __device__ __forceinline__ epv_block2 epv_keyed_block(uint32_t seed_lo, uint32_t
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += EPV_PHILOX_W0;
     k1 += EPV_PHILOX_W1;
+#ifndef EPV_PHILOX_HOISTKEYS
+    // keep the key schedule a chain of scalar adds next to its use: hoisted out of the kernels' loops the
+    // twenty round keys live in SGPRs from the first block to the last and push other values into spills
+    // (fused phase: 108 -> 91 spilled SGPRs, +1..2 % on tree.nwk; the large-tree kernels: +-0)
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
   }
   const uint64_t a = ((uint64_t)c1 << 32) | c0;
   const uint64_t c = ((uint64_t)c3 << 32) | c2;
