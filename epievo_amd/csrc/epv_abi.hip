@@ -668,10 +668,22 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
       const double est = (double)threads * c->S.B * std::min(1.0, 0.1 + c->kbar) / 2048.0;
       tpw = est >= 64.0 ? 64u : est >= 32.0 ? 32u : est >= 16.0 ? 16u : 8u;
     }
+    // the one-segment tasks (the first bucket: ~95 % on short branches) in their own lean kernel; the general
+    // one then takes the rest with a grid sized for it.  (Forward-rejection mode keeps the general kernel for
+    // everything: a flip there can need 1e5 trials, which only the wave-wide search takes in reasonable time.)
+    static const int j1_env = std::getenv("EPV_JUMPS1") ? std::atoi(std::getenv("EPV_JUMPS1")) : 1;
+    const bool j1 = j1_env != 0 && !(c->S.flags & EPV_FLAG_FORWARD_REJECTION);
     // a block (4 waves) takes 4*tpw tasks per pass; size the grid for ~1/4 of the worst case
-    const uint64_t jb = std::min<uint64_t>((max_tasks / 4u + 4u * tpw - 1u) / (4u * tpw) + 1u, 256u);
-    hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
-                       c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, 0.0, 0.0, c->d_counters);
+    if (j1) {
+      const uint64_t j1b = std::min<uint64_t>((max_tasks / 4u + 255u) / 256u + 1u, 256u);
+      const uint64_t jgb = std::min<uint64_t>((max_tasks / 16u + 4u * tpw - 1u) / (4u * tpw) + 1u, 64u);
+      hipLaunchKernelGGL(epv_mh_jumps_all_kernel, dim3(EPV_SHARDS, (unsigned)(jgb + j1b)), dim3(256), const_lds_bytes(c->S.N),
+                         c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, c->d_counters, (uint32_t)jgb);
+    } else {
+      const uint64_t jb = std::min<uint64_t>((max_tasks / 4u + 4u * tpw - 1u) / (4u * tpw) + 1u, 256u);
+      hipLaunchKernelGGL(epv_mh_jumps_kernel, dim3((unsigned)jb, EPV_SHARDS), dim3(256), const_lds_bytes(c->S.N),
+                         c->stream, c->S, (uint32_t)seed, (uint32_t)(seed >> 32), sweep, tpw, s0, 0.0, 0.0, c->d_counters, 0u);
+    }
   }
   // meta cache of the accept kernel: 5 columns x B words per lane in LDS while that stays small
   // (B <= 8: 20 KB per block next to the 24 KB of accumulators)

@@ -94,6 +94,15 @@ struct EpvIndepConst {
   double J0[4], J1[4], D0[4], D1[4];  // expectation_J / expectation_D
 };
 
+// task words of the jump kernels: branch << 40 | site; a one-segment branch may carry what the kernel
+// would otherwise load in the upper bits (epv_flush_tasks)
+#define EPV_TASK_COMPACT (1ull << 63)
+#define EPV_TASK_SELP_SHIFT 62     /* buffer the proposal is written to */
+#define EPV_TASK_START_SHIFT 61    /* its start state */
+#define EPV_TASK_SAMPLED_SHIFT 60  /* the sampled end state of its only segment */
+#define EPV_TASK_LINIT_SHIFT 59    /* start states of the left / right neighbour's path on the branch */
+#define EPV_TASK_RINIT_SHIFT 58
+
 // run-time options (epv_set_options; the same values as the public header)
 #define EPV_FLAG_REFERENCE_PROPOSAL_RATIO 1u  /* evaluate q(old)/q(new) with the reference's sums */
 #define EPV_FLAG_FORWARD_REJECTION 2u         /* state-changing segments by forward rejection too */

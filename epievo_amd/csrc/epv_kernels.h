@@ -749,11 +749,12 @@ __global__ __launch_bounds__(64, EPV_PROPOSE_WAVES) void epv_mh_propose_kernel(
 #ifndef EPV_JUMPS_WAVES
 #define EPV_JUMPS_WAVES 3   /* waves per SIMD the register allocation aims for: 3 = 168 VGPRs, no scratch since the Philox XOR3 (round 2: 26 registers spilled, 2 was as fast); 16-leaf tree -5..-8 % per phase, tree.nwk n = 3e6 -5 % */
 #endif
-__global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
-                                                           uint32_t seed_hi, uint32_t sweep,
-                                                           uint32_t tasks_per_wave, uint64_t s0,
-                                                           double indep_r0, double indep_r1,
-                                                           unsigned long long *counters) {
+// (a device function with the block's place in its grid as arguments: epv_mh_jumps_all_kernel runs it in
+// the first blocks of a launch whose other blocks take the one-segment tasks)
+__device__ __forceinline__ void epv_jumps_body(const EpvDev &S, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
+                                               uint32_t tasks_per_wave, uint64_t s0, double indep_r0, double indep_r1,
+                                               unsigned long long *counters, uint32_t skip_single, uint32_t block_x,
+                                               uint32_t grid_x, uint32_t shard) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   // per-wave cooperative-search area: task slots by rank and per-lane trial results
   __shared__ double c_len_[4][64], c_r0_[4][64], c_r1_[4][64], c_trunc_[4][64], c_tj_[4][64 * EPV_TJ];
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
            *c_nk = c_nk_[wave], *c_res = c_res_[wave], *c_tw = c_tw_[wave];
   const bool indep = indep_r0 > 0.0;   // epv_indep_update_paths: rates are not context dependent
   const bool nielsen = !(S.flags & EPV_FLAG_FORWARD_REJECTION);
-  const uint32_t shard = blockIdx.y;   // one task-list region per counter shard
+  // (`shard`: one task-list region per counter shard)
   // two regions per shard, each filled from both ends: buckets K = 1, 2, 3, >= 4 in this order
   const unsigned long long packed = counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)];
   const unsigned long long packed2 = counters[EPV_CNT_IDX(EPV_CNT_TASKS2, shard)];
@@ -790,12 +791,14 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
   const uint32_t tpw_deep = tasks_per_wave >= 32u ? tasks_per_wave / 4u : tasks_per_wave;
 #endif
   const unsigned long long n_deep = n_tasks - n1;
-  const unsigned long long W2 = (n_deep + tpw_deep - 1u) / tpw_deep, W1 = (n1 + tasks_per_wave - 1u) / tasks_per_wave;
-  for (unsigned long long cidx = (unsigned long long)blockIdx.x * 4u + wave; cidx < W1 + W2;
-       cidx += (unsigned long long)gridDim.x * 4u) {
+  // skip_single: the one-segment tasks (the first bucket) have been done by epv_mh_jumps1_kernel
+  const unsigned long long first_task = skip_single ? n0 : 0ull;
+  const unsigned long long W2 = (n_deep + tpw_deep - 1u) / tpw_deep, W1 = (n1 - first_task + tasks_per_wave - 1u) / tasks_per_wave;
+  for (unsigned long long cidx = (unsigned long long)block_x * 4u + wave; cidx < W1 + W2;
+       cidx += (unsigned long long)grid_x * 4u) {
     const bool deep_chunk = cidx < W2;
     const uint32_t my_tpw = deep_chunk ? tpw_deep : tasks_per_wave;
-    const unsigned long long base = deep_chunk ? n1 + cidx * tpw_deep : (cidx - W2) * tasks_per_wave;
+    const unsigned long long base = deep_chunk ? n1 + cidx * tpw_deep : first_task + (cidx - W2) * tasks_per_wave;
     const unsigned long long limit = deep_chunk ? n_tasks : n1;
     const unsigned long long ti = base + (unsigned)lane;
     bool active = (uint32_t)lane < my_tpw && ti < limit;
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
                                       : ti < n2 ? tasks[S.task_cap + (ti - n1)]
                                                 : tasks[2ull * S.task_cap - 1ull - (ti - n2)];
       site = task & 0xffffffffffull;
-      b = (uint32_t)(task >> 40);
+      b = (uint32_t)(task >> 40) & 0xfffu;     // (the bits above may describe a one-segment branch: epv_mh_jumps1_kernel)
       node = b + 1u;
       gsite = (uint32_t)(S.g0 + site);
       const uint32_t selP = S.sel[site] ^ 1u;
@@ -953,6 +956,94 @@ __global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvD
       }
     }
   }
+}
+
+
+__global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_kernel(EpvDev S, uint32_t seed_lo,
+                                                           uint32_t seed_hi, uint32_t sweep,
+                                                           uint32_t tasks_per_wave, uint64_t s0,
+                                                           double indep_r0, double indep_r1,
+                                                           unsigned long long *counters, uint32_t skip_single = 0u) {
+  epv_jumps_body(S, seed_lo, seed_hi, sweep, tasks_per_wave, s0, indep_r0, indep_r1, counters, skip_single, blockIdx.x,
+                 gridDim.x, blockIdx.y);
+}
+
+// =========================================================================
+//  The one-segment tasks (no neighbour jump on the branch: the first bucket of the lists, ~95 % of the
+//  tasks on short branches) in a kernel of their own: no merge state, no cooperative search, a third
+//  of the general kernel's work per task.  A task word written by epv_flush_tasks with EPV_TASK_COMPACT
+//  carries everything; any other is completed from the meta words.  The trials are the general kernel's
+//  (scan_trials): the first non-failing one wins -- searched by this lane alone, window after window
+//  (with Nielsen's method a trial succeeds with probability ~1/2 or better; forward-rejection mode,
+//  where a flip can need 1e5 trials, keeps the general kernel and its wave-wide search).
+// =========================================================================
+__device__ __forceinline__ void epv_jumps1_body(const EpvDev &S, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep,
+                                                uint64_t s0, unsigned long long *counters, uint32_t block_x, uint32_t grid_x,
+                                                uint32_t shard) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  stage_constants(S, s_mem);
+  const double *s_rates = s_mem, *s_blen = s_mem + 20;
+  const unsigned long long n0 = counters[EPV_CNT_IDX(EPV_CNT_TASKS, shard)] & 0xffffffffull;
+  const unsigned long long *tasks = S.tasks + (unsigned long long)shard * 2u * S.task_cap;
+  const uint64_t n = S.n;
+  const uint32_t B = S.B, C = S.C;
+  for (unsigned long long ti = (unsigned long long)block_x * blockDim.x + threadIdx.x; ti < n0;
+       ti += (unsigned long long)grid_x * blockDim.x) {
+    const unsigned long long task = tasks[ti];
+    const uint64_t site = task & 0xffffffffffull;
+    const uint32_t b = (uint32_t)(task >> 40) & 0xfffu, node = b + 1u;
+    const uint32_t gsite = (uint32_t)(S.g0 + site);
+    const uint64_t ptid = (site - s0) / 3u;
+    uint32_t selP, start_state, sampled, li, ri;
+    if (task & EPV_TASK_COMPACT) {
+      selP = (uint32_t)(task >> EPV_TASK_SELP_SHIFT) & 1u;
+      start_state = (uint32_t)(task >> EPV_TASK_START_SHIFT) & 1u;
+      sampled = (uint32_t)(task >> EPV_TASK_SAMPLED_SHIFT) & 1u;
+      li = (uint32_t)(task >> EPV_TASK_LINIT_SHIFT) & 1u;
+      ri = (uint32_t)(task >> EPV_TASK_RINIT_SHIFT) & 1u;
+    } else {
+      selP = S.sel[site] ^ 1u;
+      li = (uint32_t)(S.meta[meta_idx(S, S.sel[site - 1], b, site - 1)] >> EPV_INIT_SHIFT);
+      ri = (uint32_t)(S.meta[meta_idx(S, S.sel[site + 1], b, site + 1)] >> EPV_INIT_SHIFT);
+      start_state = (uint32_t)(S.meta[meta_idx(S, selP, b, site)] >> EPV_INIT_SHIFT);
+      sampled = (uint32_t)(S.prop_states[((uint64_t)b * S.phase_cap + ptid) * S.W] & 1ull);
+    }
+    const uint32_t trip0 = 4u * li + ri;
+    const double len = s_blen[node] - 0.0;      // (the only segment: seg_end - seg_start with seg_start = 0)
+    const double r0 = s_rates[trip0], r1 = s_rates[trip0 | 2u];
+    // sample_trunc_exp's 1 - exp(-rate_a T) (EndCondSampling.cpp:577-580), state changes only
+    const double trunc = (sampled != start_state) ? 1.0 - epv_exp(-(start_state ? r1 : r0) * len) : 0.0;
+    double *dst = S.jumps + ((uint64_t)selP * B + b) * C * n + site;
+    uint32_t cnt = 0u;
+    bool ovf = false;
+    for (uint32_t t0 = 1u;; t0 += EPV_INLINE_TRIALS) {
+      uint32_t njt, tw;
+      const int oc = scan_trials(seed_lo, seed_hi, gsite, sweep, node, 0u, t0, EPV_INLINE_TRIALS, start_state, sampled, len,
+                                 r0, r1, trunc, C, dst, n, 0xffffffffu, 0.0, tw, njt, true);
+      if (oc == TRIAL_OK) { cnt = njt; break; }
+      if (oc == TRIAL_OVERFLOW) { ovf = true; break; }
+    }
+    if (ovf) {
+      cnt = (start_state ^ sampled) & 1u;   // keep the end-state parity; the proposal is rejected
+      S.prop_flag[ptid] = 1u;
+    }
+    S.meta[meta_idx(S, selP, b, site)] = (epv_meta_t)((start_state << EPV_INIT_SHIFT) | cnt);
+  }
+}
+
+// Both in ONE launch: the first `general_blocks` blocks of a grid row run the general kernel on the tasks
+// of two and more segments -- few, but each a long dependent chain: alone they were a 58 us launch for 5 %
+// of the tasks of the 16-leaf tree -- and the others the one-segment tasks next to them.
+__global__ __launch_bounds__(256, EPV_JUMPS_WAVES) void epv_mh_jumps_all_kernel(EpvDev S, uint32_t seed_lo, uint32_t seed_hi,
+                                                                                 uint32_t sweep, uint32_t tasks_per_wave,
+                                                                                 uint64_t s0, unsigned long long *counters,
+                                                                                 uint32_t general_blocks) {
+  // grid (shards, blocks per shard): blocks are dispatched x-fastest, so every shard's general blocks -- the
+  // long chains -- are on the chip before the first one-segment block
+  if (blockIdx.y < general_blocks)
+    epv_jumps_body(S, seed_lo, seed_hi, sweep, tasks_per_wave, s0, 0.0, 0.0, counters, 1u, blockIdx.y, general_blocks, blockIdx.x);
+  else
+    epv_jumps1_body(S, seed_lo, seed_hi, sweep, s0, counters, blockIdx.y - general_blocks, gridDim.y - general_blocks, blockIdx.x);
 }
 
 #include "epv_jumps2.h"

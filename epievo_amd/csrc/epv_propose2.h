@@ -77,10 +77,17 @@ __global__ void epv_segtab_kernel(EpvDev S, double *tab) {
 // with similar loop counts: a shard has two regions, each filled from BOTH ends (counts packed
 // lo/hi in one word) -- region 0: K = 1 from the front, K = 2 from the back; region 1: K = 3
 // from the front, K >= 4 from the back.  One atomic per wave and region reserves the slots.
+// A task word is branch << 40 | site.  A ONE-SEGMENT branch (no neighbour jump) may carry everything the
+// jump kernels would otherwise load -- buffer of the proposal, start state, sampled end state, the
+// neighbours' start states -- in its upper bits (EPV_TASK_COMPACT, epv_device.h): epv_mh_jumps1_kernel
+// then starts its trials one round trip after reading the word.  `compact` marks those branches; selP,
+// xstart, xsamp, xL, xR are the values, one bit per branch like `dirty`.
 __device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long long *counters,
                                                 unsigned long long dirty, unsigned long long multi,
                                                 unsigned long long deep, uint32_t b, uint64_t site, int lane,
-                                                uint32_t shard) {
+                                                uint32_t shard, unsigned long long compact = 0ull, uint32_t selP = 0u,
+                                                unsigned long long xstart = 0ull, unsigned long long xsamp = 0ull,
+                                                unsigned long long xL = 0ull, unsigned long long xR = 0ull) {
 #pragma unroll
   for (uint32_t reg = 0; reg < 2u; ++reg) {
     const unsigned long long mine_reg = reg ? (dirty & deep) : (dirty & ~deep);
@@ -101,7 +108,11 @@ __device__ __forceinline__ void epv_flush_tasks(const EpvDev &S, unsigned long l
       while (d) {
         const uint32_t bit = (uint32_t)(__ffsll((long long)d) - 1);
         d &= d - 1ull;
-        const unsigned long long t = ((unsigned long long)((b & ~63u) + bit) << 40) | site;
+        unsigned long long t = ((unsigned long long)((b & ~63u) + bit) << 40) | site;
+        if ((compact >> bit) & 1ull)
+          t |= EPV_TASK_COMPACT | ((unsigned long long)selP << EPV_TASK_SELP_SHIFT) |
+               (((xstart >> bit) & 1ull) << EPV_TASK_START_SHIFT) | (((xsamp >> bit) & 1ull) << EPV_TASK_SAMPLED_SHIFT) |
+               (((xL >> bit) & 1ull) << EPV_TASK_LINIT_SHIFT) | (((xR >> bit) & 1ull) << EPV_TASK_RINIT_SHIFT);
         if ((multi >> bit) & 1ull) region[slotB--] = t;
         else region[slotA++] = t;
       }

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
 
     // ---- 5. downward sampling of the segment END STATES (:180-255), level by level from the root;
     //         the jump times are drawn by epv_mh_jumps_kernel for the dirty branches only
-    unsigned long long mEnd = 0ull, dirty = 0ull, multi = 0ull, deep = 0ull;
+    unsigned long long mEnd = 0ull, mStart = 0ull, dirty = 0ull, multi = 0ull, deep = 0ull;
     const uint64_t pcW = (uint64_t)S.phase_cap * S.W, tidW = tid * S.W;
     bool ident = true;
     if (run) {
@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
               b_multi = (r >> 4) & 1u; b_deep = (r >> 5) & 1u;
             }
             mEnd |= (unsigned long long)prev << node;     // proposal end state for the children
+            mStart |= (unsigned long long)start_state << node;
             // same as the current path?  (no jumps on either, same start state)
             ident = ident && clean && !((mMj >> node) & 1ull) && ((uint32_t)(mM >> node) & 1u) == start_state;
             if (!clean) {
@@ -624,7 +625,9 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
         }
       }
     }
-    epv_flush_tasks(S, counters, dirty, multi, deep, B - 1u, site, lane, my_shard);
+    // (a dirty branch of one segment hands the jump kernel all it needs in the task word)
+    epv_flush_tasks(S, counters, dirty, multi, deep, B - 1u, site, lane, my_shard, dirty & ~(mH >> 1), ((selbits >> 1) & 1u) ^ 1u,
+                    mStart >> 1, mEnd >> 1, mL >> 1, mR >> 1);
     P2_MARK(6);
 
     // ---- 7. hand-over.  A proposal equal to the current path is accepted with probability one and
