@@ -68,6 +68,10 @@ __device__ __forceinline__ double triple_llh_grouped(const EpvDev &S, const doub
       wm[q] = in ? (uint32_t)S.meta[mm0 + off] : 0u;
       wr[q] = in ? (uint32_t)S.meta[mr0 + off] : 0u;
     }
+    // all meta words in before the first conditional load goes out: behind a load under a lane mask the
+    // compiler can no longer count what is in flight and waits for EVERYTHING at the next use of a meta
+    // word -- the first jumps would leave one round trip apart instead of together
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
     double tl[G], tm[G], tr[G];
 #pragma unroll
     for (uint32_t q = 0; q < G; ++q) {

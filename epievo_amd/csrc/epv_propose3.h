@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
         Lj[q] = S.jumps + jl + (uint64_t)b * Cn;
         Rj[q] = S.jumps + jr + (uint64_t)b * Cn;
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): every meta word in before the first conditional load (epv_accept3.h)
       double tl0[NP], tr0[NP];
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
