@@ -49,7 +49,7 @@ def main():
     tj = os.path.join(here, "traffic.json")
     data = json.load(open(tj)) if os.path.exists(tj) else {}
     parts = [r for r in rows if r[0] in ("epv_mh_phase_kernel", "epv_mh_propose_kernel", "epv_mh_propose2_kernel",
-                                         "epv_mh_propose3_kernel", "epv_mh_jumps_kernel", "epv_mh_accept_kernel",
+                                         "epv_mh_propose3_kernel", "epv_mh_jumps_kernel", "epv_mh_jumps_all_kernel", "epv_mh_accept_kernel",
                                          "epv_mh_accept3_kernel")]
     mh = ("+".join(r[0] for r in parts), parts[0][1], sum(r[2] for r in parts), sum(r[3] for r in parts))
     data[config] = {"kernel": mh[0], "round": tag,

@@ -24,7 +24,7 @@ import pmc_load  # noqa: E402
 
 CLOCK_GHZ = 2.4      # MI355X peak engine clock
 SIMDS = 1024
-MH = ("epv_mh_propose_kernel", "epv_mh_propose2_kernel", "epv_mh_propose3_kernel", "epv_mh_jumps_kernel",
+MH = ("epv_mh_propose_kernel", "epv_mh_propose2_kernel", "epv_mh_propose3_kernel", "epv_mh_jumps_kernel", "epv_mh_jumps_all_kernel",
       "epv_mh_accept_kernel", "epv_mh_accept3_kernel")
 
 
