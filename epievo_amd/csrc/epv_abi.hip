@@ -219,7 +219,7 @@ int plan_p2(epv_ctx *c) {
   // case of every wave within 4 GB
   // sites per wave: halve while every SIMD could still get two waves
   uint32_t f_lanes = 64u;
-  if (const char *e = std::getenv("EPV_FUSED_LANES")) { const int v = std::atoi(e); if (v == 16 || v == 32 || v == 64) f_lanes = (uint32_t)v; }
+  if (const char *e = std::getenv("EPV_FUSED_LANES")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) f_lanes = (uint32_t)v; }
   else while (f_lanes > 16u && (c->S.phase_cap + f_lanes / 2u - 1u) / (f_lanes / 2u) <= 2048u) f_lanes /= 2u;
   const uint64_t phase_waves = (c->S.phase_cap + 63u) / 64u;
   const uint64_t f_seg_cap = 64ull * B * (2u * C + 1u), f_bt_cap = 64ull * B;

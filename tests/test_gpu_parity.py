@@ -39,7 +39,8 @@ def test_reset_and_roundtrip(cfg, n):
 
 @pytest.mark.parametrize("cfg,n,sweeps", [("tree", 64, 3), ("tree", 1000, 3), ("pair", 1000, 3),
                                           ("tree", 20011, 2), ("pair", 20011, 2),
-                                          ("bal16", 3000, 2), ("tree", 3, 2), ("tree", 4, 2),
+                                          ("bal16", 3000, 2), ("bal16", 3, 2), ("bal16", 5, 2), ("bal16", 67, 2),
+                                          ("cat20", 200, 2), ("tree", 3, 2), ("tree", 4, 2),
                                           ("tree", 5, 2), ("pair", 6, 2), ("star4", 3000, 3),
                                           ("multi", 3000, 3), ("cat6", 3000, 3)])
 def test_sweeps_bit_exact(cfg, n, sweeps):
