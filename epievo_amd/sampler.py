@@ -200,10 +200,10 @@ class DeviceSampler:
 
     PHASE_KERNELS = {
         0: "epv_mh_propose_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel",
-        1: "epv_mh_propose2_kernel + epv_mh_jumps_kernel + epv_mh_accept_kernel",
+        1: "epv_mh_propose2_kernel + epv_mh_jumps_all_kernel + epv_mh_accept_kernel",
         2: "epv_mh_propose2_kernel + epv_seg_search_kernel + epv_seg_assemble_kernel + epv_mh_accept_kernel",
         3: "epv_mh_propose2_kernel<fused>: proposal, segment search, assembly and acceptance in one launch",
-        4: "epv_mh_propose3_kernel + epv_mh_jumps_kernel + epv_mh_accept3_kernel",
+        4: "epv_mh_propose3_kernel + epv_mh_jumps_all_kernel + epv_mh_accept3_kernel",
     }
 
     def phase_mode(self):

@@ -121,7 +121,7 @@ int epv_get_options(epv_ctx *ctx, uint32_t *flags);
  *     proposal arithmetic), 1 = epv_mh_propose2_kernel + jumps + accept, 2 = epv_mh_propose2_kernel +
  *     epv_seg_search_kernel + epv_seg_assemble_kernel + accept (long branches), 3 = the fused phase:
  *     one epv_mh_propose2_kernel launch that also samples the jump times and accepts (launches of few
- *     waves), 4 = epv_mh_propose3_kernel + epv_mh_jumps_kernel + epv_mh_accept3_kernel (large trees:
+ *     waves), 4 = epv_mh_propose3_kernel + epv_mh_jumps_all_kernel + epv_mh_accept3_kernel (large trees:
  *     the tree walked level by level, heavy branches one lane each, a lane per (site, triple) in the
  *     acceptance).  No reference counterpart. */
 enum { EPV_PHASE_V1 = 0, EPV_PHASE_V2 = 1, EPV_PHASE_V2_SEGMENTS = 2, EPV_PHASE_FUSED = 3, EPV_PHASE_V3 = 4 };
