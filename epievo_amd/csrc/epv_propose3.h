@@ -27,7 +27,7 @@
 //     merged (Segment.cpp:35-79) and evaluated densely as in epv_mh_propose2_kernel; then, level by
 //     level behind the nodes' pass, a pair lane runs the branch's pruning chain from registers and --
 //     the uniforms of a segment being fixed -- the chain of end states for BOTH start states, leaving
-//     p.front (16 B) and four result bits in LDS for the lanes that own the sites.  The sequential
+//     p.front (16 B) and six result bits in LDS for the lanes that own the sites.  The sequential
 //     parts never iterate over segments.
 // LDS per wave: 6.9 KB (pair list and results) instead of 19.5 (second kernel); global traffic per
 // wave: the 14 q rows and the heavy records.
