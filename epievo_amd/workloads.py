@@ -54,6 +54,8 @@ def config(name):
         return host.Tree.single_branch(1.0)
     if name == "bal16":
         return host.Tree.balanced(16, 0.05)
+    if name == "bal8":           # 15 nodes: between the trees the LDS record pool was made for and the large-tree kernels
+        return host.Tree.balanced(8, 0.05)
     if name == "bal32":          # 63 nodes: the widest tree the large-tree kernels take (node masks are one word)
         return host.Tree.balanced(32, 0.03)
     if name == "cat20":          # a caterpillar of 20 leaves: 39 nodes, 19 levels
