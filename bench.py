@@ -234,7 +234,7 @@ def main():
     ap.add_argument("--sites", type=int, default=0,
                     help="sites per GPU; 0 = 1e6 on one GPU (BASELINE config 3, the metric's), 1.25e6 per GPU on "
                          "several (8 GPUs = BASELINE config 4's n = 1e7)")
-    ap.add_argument("--config", default="tree", choices=["tree", "pair", "bal16", "bal8", "bal32", "cat20", "cat6", "star4"])
+    ap.add_argument("--config", default="tree", choices=["tree", "pair", "bal16", "bal8", "bal32", "bal64", "cat20", "cat6", "star4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-leg", action="store_true",
                     help="skip the extra steps in reference-arithmetic mode (profiling runs)")

@@ -274,7 +274,7 @@ int plan_p2(epv_ctx *c) {
 int plan_p3(epv_ctx *c) {
   c->p3 = false;
   const uint32_t B = c->S.B, C = c->S.C, N = c->S.N;
-  if (c->use_p3 == 0 || !c->use_p2 || N > 64u || N < 2u) return EPV_OK;
+  if (c->use_p3 == 0 || !c->use_p2 || N > 128u || N < 2u) return EPV_OK;     // (node masks of one or two 64-bit words)
   if (c->use_p3 < 0 && !c->p2_gpool) return EPV_OK;     // the LDS pool is the better place while it fits
   // per node: parent, children, depth; q rows for the internal nodes below the root
   std::vector<uint32_t> depth(N, 0u), c1(N, 0u), c2(N, 0u), kids(N, 0u), qrow(N, 0u);
@@ -291,13 +291,13 @@ int plan_p3(epv_ctx *c) {
     if (kids[node] > 2u) return EPV_OK;                  // two child fields per node word
     if (c->subtree[node] != 1u) qrow[node] = qrows++;
   }
-  if (max_depth > 62u) return EPV_OK;
+  if (qrows > 63u) return EPV_OK;                        // (six bits in the node word)
   // tables: node words [N] | internal nodes deepest first [n_up] | their level starts [D + 2] |
   //         all nodes but the root by depth [N - 1] | their level starts [D + 2]
   std::vector<uint32_t> tab;
   for (uint32_t node = 0; node < N; ++node)
-    tab.push_back(c->parent[node] | (c1[node] << 6) | (c2[node] << 12) | (qrow[node] << 18) |
-                  ((c->subtree[node] == 1u ? 1u : 0u) << 24) | (depth[node] << 25));
+    tab.push_back(c->parent[node] | (c1[node] << 7) | (c2[node] << 14) | (qrow[node] << 21) |
+                  ((c->subtree[node] == 1u ? 1u : 0u) << 27));
   std::vector<uint32_t> up, upstart(max_depth + 2u, 0u), dn, dnstart(max_depth + 2u, 0u);
   for (uint32_t d = max_depth + 1u; d-- > 0u;) {        // upstart[d + 1] .. upstart[d] = internal nodes of depth d
     if (d <= max_depth && d >= 1u)
@@ -319,14 +319,17 @@ int plan_p3(epv_ctx *c) {
   tab.insert(tab.end(), dn.begin(), dn.end());
   tab.insert(tab.end(), dnstart.begin(), dnstart.end());
   for (uint32_t g = 0; g < max_depth; ++g) {            // pair groups: leaves, then internal nodes by depth
-    uint64_t m = 0;
+    uint64_t m = 0, m2 = 0;      // nodes 0..63, 64..127
     for (uint32_t node = 1; node < N; ++node) {
       const bool leaf = c->subtree[node] == 1u;
-      if (g == 0u ? leaf : (!leaf && depth[node] == g)) m |= 1ull << node;
+      if (g == 0u ? leaf : (!leaf && depth[node] == g)) (node < 64u ? m : m2) |= 1ull << (node & 63u);
     }
     tab.push_back((uint32_t)m);
     tab.push_back((uint32_t)(m >> 32));
+    tab.push_back((uint32_t)m2);
+    tab.push_back((uint32_t)(m2 >> 32));
   }
+  for (uint32_t node = 0; node < N; ++node) tab.push_back(depth[node]);
   const double lam = 2.0 * c->kbar;
   const double heavy_per_branch = (1.0 + lam) - std::exp(-lam);
   const uint64_t worst_heavy = (uint64_t)B * (2u * C + 1u);
@@ -345,7 +348,8 @@ int plan_p3(epv_ctx *c) {
   if (need * sizeof(double) > (24ull << 30)) return EPV_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   c->gpool3_need = need;
-  if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 512u * sizeof(uint32_t)));
+  if (tab.size() > 2048u) return EPV_OK;
+  if (!c->d_nodetab) HIP_TRY(c, hipMalloc(&c->d_nodetab, 2048u * sizeof(uint32_t)));
   if (!c->d_slabflags) {
     HIP_TRY(c, hipMalloc(&c->d_slabflags, 8u * 256u * sizeof(uint32_t)));
     HIP_TRY(c, hipMemset(c->d_slabflags, 0, 8u * 256u * sizeof(uint32_t)));
@@ -619,7 +623,8 @@ int launch_phase(epv_ctx *c, int colour, uint64_t seed, uint32_t sweep) {
     list_mode = 1u + (c->phase_parity & 1u);
     const unsigned pb = (unsigned)((threads + 255u) / 256u);
     { const int rc3 = ensure_slab(c, &c->d_gpool3, &c->gpool3_cap, c->gpool3_need); if (rc3) return rc3; }
-    hipLaunchKernelGGL(epv_mh_propose3_kernel<false>, dim3(pb), dim3(256), c->p3_lds, c->stream, c->S, (uint32_t)colour,
+    auto k3 = c->S.N > 64u ? epv_mh_propose3_kernel<2> : epv_mh_propose3_kernel<1>;
+    hipLaunchKernelGGL(k3, dim3(pb), dim3(256), c->p3_lds, c->stream, c->S, (uint32_t)colour,
                        (uint32_t)seed, (uint32_t)(seed >> 32), sweep, first, last, own_lo, own_hi, c->p3_list_cap,
                        c->p3_qrows, c->p3_nup, c->p3_depth, c->phase_parity & 1u, c->d_counters, c->d_gpool3, c->d_segtab,
                        c->d_nodetab, c->d_slabflags, c->p3_slots);
@@ -786,8 +791,10 @@ EPV_API epv_ctx *epv_create(int device_id) {
     return nullptr;
   }
   // the MH kernel asks for more dynamic LDS than the 64 KiB default
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose3_kernel<false>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose3_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);   // (it has static LDS too)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose3_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(epv_mh_propose2_kernel<false, true, false>),

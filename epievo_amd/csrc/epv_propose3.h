@@ -16,7 +16,7 @@
 // Here nothing about a (node, lane) pair lives in memory at all unless the branch is heavy:
 //   * what the recursions need to know about a branch -- the neighbours' start states, this path's
 //     start state / jump parity / "has jumps", "a neighbour jumps on it" (heavy) -- are six 64-bit
-//     masks per lane, one bit per node (N <= 64), filled from one batch of meta-word loads;
+//     masks per lane, one bit per node (one or two words: N <= 128), filled from one batch of meta-word loads;
 //   * the tree is walked LEVEL BY LEVEL, not node by node: the nodes of a level are independent, so
 //     their global loads are issued together and a wave waits once per level (4 on the 16-leaf tree)
 //     instead of once or twice per node (30);
@@ -32,20 +32,72 @@
 // LDS per wave: 6.9 KB (pair list and results) instead of 19.5 (second kernel); global traffic per
 // wave: the 14 q rows and the heavy records.
 //
-// Preconditions (plan_p3, epv_abi.hip): N <= 64, every node but the root has at most two children.
+// Preconditions (plan_p3, epv_abi.hip): N <= 128 (node masks of one or two 64-bit words: the kernel is a
+// template on the word count), every node but the root has at most two children.
 
 #define EPV_P3_PCAP 256u   /* heavy (lane, node) pairs a wave lists per round (at least 64: one lane's worst case) */
 
-// s_tree[node]: parent | first child << 6 | second child << 12 | q row << 18 | leaf << 24 | depth << 25
-#define EPV_P3_PARENT(w) ((w) & 63u)
-#define EPV_P3_CHILD1(w) (((w) >> 6) & 63u)
-#define EPV_P3_CHILD2(w) (((w) >> 12) & 63u)
-#define EPV_P3_QROW(w) (((w) >> 18) & 63u)
-#define EPV_P3_LEAF(w) (((w) >> 24) & 1u)
-#define EPV_P3_DEPTH(w) (((w) >> 25) & 63u)
-// pair word: lane | node << 6 | segments << 12 | first record << 32 | leaf state << 62
+// s_tree[node]: parent | first child << 7 | second child << 14 | q row << 21 | leaf << 27; s_dep[node]: depth
+#define EPV_P3_PARENT(w) ((w) & 127u)
+#define EPV_P3_CHILD1(w) (((w) >> 7) & 127u)
+#define EPV_P3_CHILD2(w) (((w) >> 14) & 127u)
+#define EPV_P3_QROW(w) (((w) >> 21) & 63u)
+#define EPV_P3_LEAF(w) (((w) >> 27) & 1u)
+// pair word: lane | node << 6 | segments << 13 | first record << 32 | leaf state << 62
+#define EPV_P3_PAIR_NODE(pr) (((uint32_t)(pr) >> 6) & 127u)
+#define EPV_P3_PAIR_K(pr) (((uint32_t)(pr) >> 13) & 0x7ffffu)
 // s_pb[pair]: end state for start state 0 | clean << 1 | end state for start 1 << 2 | clean << 3 |
 //             (K == 2 or K >= 4) << 4 | (K >= 3) << 5   (the task buckets of epv_flush_tasks)
+
+// One bit per node in W 64-bit words (W = 1: up to 64 nodes, W = 2: up to 128).  Node indices are
+// wave-uniform wherever these are called with one, so the word select is scalar work.
+template <int W> struct P3Mask { unsigned long long w[W]; };
+template <int W> __device__ __forceinline__ void p3_zero(P3Mask<W> &m) {
+#pragma unroll
+  for (int q = 0; q < W; ++q) m.w[q] = 0ull;
+}
+template <int W> __device__ __forceinline__ uint32_t p3_get(const P3Mask<W> &m, uint32_t i) {
+  if constexpr (W == 1) return (uint32_t)(m.w[0] >> i) & 1u;
+  else {
+    unsigned long long x = m.w[0];
+#pragma unroll
+    for (int q = 1; q < W; ++q) x = (i >> 6) == (uint32_t)q ? m.w[q] : x;
+    return (uint32_t)(x >> (i & 63u)) & 1u;
+  }
+}
+template <int W> __device__ __forceinline__ void p3_or(P3Mask<W> &m, uint32_t i, uint32_t bit) {
+  if constexpr (W == 1) m.w[0] |= (unsigned long long)bit << i;
+  else {
+#pragma unroll
+    for (int q = 0; q < W; ++q) m.w[q] |= (i >> 6) == (uint32_t)q ? (unsigned long long)bit << (i & 63u) : 0ull;
+  }
+}
+// popcount of a & g, and of a & g restricted to the bits below i
+template <int W> __device__ __forceinline__ uint32_t p3_count(const P3Mask<W> &a, const P3Mask<W> &g) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int q = 0; q < W; ++q) c += (uint32_t)__popcll(a.w[q] & g.w[q]);
+  return c;
+}
+template <int W> __device__ __forceinline__ uint32_t p3_count_below(const P3Mask<W> &a, const P3Mask<W> &g, uint32_t i) {
+  if constexpr (W == 1) return (uint32_t)__popcll(a.w[0] & g.w[0] & ((1ull << i) - 1ull));
+  else {
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+      const unsigned long long below = (i >> 6) > (uint32_t)q ? ~0ull : (i >> 6) == (uint32_t)q ? (1ull << (i & 63u)) - 1ull : 0ull;
+      c += (uint32_t)__popcll(a.w[q] & g.w[q] & below);
+    }
+    return c;
+  }
+}
+// the mask shifted down by one bit (node masks -> branch masks: branch b hangs above node b + 1)
+template <int W> __device__ __forceinline__ P3Mask<W> p3_shr1(const P3Mask<W> &m) {
+  P3Mask<W> r;
+#pragma unroll
+  for (int q = 0; q < W; ++q) r.w[q] = (m.w[q] >> 1) | (q + 1 < W ? m.w[q + 1 < W ? q + 1 : q] << 63 : 0ull);
+  return r;
+}
 
 #ifndef EPV_P3_KREG
 #define EPV_P3_KREG 3u   /* segments of a heavy branch the pair pass keeps in registers (8 doubles each); longer ones go through memory */
@@ -56,7 +108,7 @@
 #ifndef EPV_P3_MINBLOCKS
 #define EPV_P3_MINBLOCKS 3   /* blocks of four waves per CU the register allocation aims for (<= 168 VGPRs) */
 #endif
-template <bool DUMMY>
+template <int W>
 __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     EpvDev S, uint32_t colour, uint32_t seed_lo, uint32_t seed_hi, uint32_t sweep, uint64_t first,
     uint64_t last, uint64_t own_first, uint64_t own_last, uint32_t list_cap, uint32_t n_qrows, uint32_t n_up,
@@ -74,8 +126,9 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
   // tree tables: node words [N], internal nodes deepest level first [n_up] with level starts
   // [depth + 2] (level d from s_upstart[d + 1] to s_upstart[d]), all nodes but the root by depth
   // [N - 1] with level starts [depth + 2] (level d from s_dnstart[d] to s_dnstart[d + 1])
-  // and the node masks of the pair groups [2 * depth] (group 0 = leaves, d = internal nodes of depth d)
-  const uint32_t tree_words = N + n_up + (depth + 2u) + (N - 1u) + (depth + 2u) + 2u * depth;
+  // the node masks of the pair groups [4 * depth] (group 0 = leaves, d = internal nodes of depth d) and
+  // the nodes' depths [N]
+  const uint32_t tree_words = N + n_up + (depth + 2u) + (N - 1u) + (depth + 2u) + 4u * depth + N;
   const uint32_t tree_dbl = (tree_words + 1u) / 2u;
   // per wave: p.front and result bits of the pairs, each lane's first slot per group, the groups' starts
   const uint32_t goff_dbl = (depth * 64u * 2u + 7u) / 8u, gstart_dbl = (depth + 2u + 1u) / 2u;
@@ -86,15 +139,19 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
   uint32_t *s_tree = reinterpret_cast<uint32_t *>(s_mem + const_dbl + tab_dbl);
   const uint32_t *s_up = s_tree + N, *s_upstart = s_up + n_up;
   const uint32_t *s_dn = s_upstart + (depth + 2u), *s_dnstart = s_dn + (N - 1u);
-  const uint32_t *s_gmask = s_dnstart + (depth + 2u);
+  const uint32_t *s_gmask = s_dnstart + (depth + 2u), *s_dep = s_gmask + 4u * depth;
   double *s_pf = s_mem + const_dbl + tab_dbl + tree_dbl + (size_t)wave_id * wave_dbl;
   uint8_t *s_pb = reinterpret_cast<uint8_t *>(s_pf + EPV_P3_PCAP * 2u);
   uint16_t *s_goff = reinterpret_cast<uint16_t *>(s_pf + EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u);
   uint32_t *s_gstart = reinterpret_cast<uint32_t *>(s_pf + EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u + goff_dbl);
   // the pair list (read by five passes: in LDS, a round trip less in each)
   unsigned long long *plist = reinterpret_cast<unsigned long long *>(s_pf + EPV_P3_PCAP * 2u + EPV_P3_PCAP / 8u + goff_dbl + gstart_dbl);
-  auto group_mask = [&](uint32_t g) __attribute__((always_inline)) -> unsigned long long {
-    return (unsigned long long)s_gmask[2u * g] | ((unsigned long long)s_gmask[2u * g + 1u] << 32);
+  auto group_mask = [&](uint32_t g) __attribute__((always_inline)) -> P3Mask<W> {
+    P3Mask<W> m;
+#pragma unroll
+    for (int q = 0; q < W; ++q)
+      m.w[q] = (unsigned long long)s_gmask[4u * g + 2u * q] | ((unsigned long long)s_gmask[4u * g + 2u * q + 1u] << 32);
+    return m;
   };
   const int lane = epv_lane();
   const uint32_t my_shard = (blockIdx.x * (blockDim.x >> 6) + wave_id) & (EPV_SHARDS - 1u);
@@ -148,7 +205,8 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
   const uint64_t site_lane0 = s0 + 3u * (uint64_t)(tid32 - (uint32_t)lane);
   // ---- 0. the meta words of the three columns, in batches of independent loads, condensed to six
   //         masks (bit `node` = the branch above the node)
-  unsigned long long mR = 0ull, mL = 0ull, mM = 0ull, mMp = 0ull, mMj = 0ull, mH = 0ull;
+  P3Mask<W> mR, mL, mM, mMp, mMj, mH;
+  p3_zero(mR); p3_zero(mL); p3_zero(mM); p3_zero(mMp); p3_zero(mMj); p3_zero(mH);
   uint32_t heavy = 0, n_pairs = 0;
   if (valid) {
     const uint64_t mbaseL = (selL ? Bn : 0ull) + (site - 1), mbaseR = (selR ? Bn : 0ull) + (site + 1);
@@ -160,15 +218,15 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
       const uint32_t wM = S.meta[mbaseM + (uint64_t)b * n];
       const uint32_t K = (wL & EPV_NJ_MASK) + (wR & EPV_NJ_MASK) + 1u;
       const uint32_t node = b + 1u;
-      mR |= (unsigned long long)(wR >> EPV_INIT_SHIFT) << node;
-      mL |= (unsigned long long)(wL >> EPV_INIT_SHIFT) << node;
-      mM |= (unsigned long long)(wM >> EPV_INIT_SHIFT) << node;
-      mMp |= (unsigned long long)(wM & 1u) << node;
-      mMj |= (unsigned long long)((wM & EPV_NJ_MASK) ? 1u : 0u) << node;
-      if (K >= 2u) { mH |= 1ull << node; heavy += K; ++n_pairs; }
+      p3_or(mR, node, wR >> EPV_INIT_SHIFT);
+      p3_or(mL, node, wL >> EPV_INIT_SHIFT);
+      p3_or(mM, node, wM >> EPV_INIT_SHIFT);
+      p3_or(mMp, node, wM & 1u);
+      p3_or(mMj, node, (wM & EPV_NJ_MASK) ? 1u : 0u);
+      if (K >= 2u) { p3_or(mH, node, 1u); heavy += K; ++n_pairs; }
     }
   }
-  const uint32_t root_state = (uint32_t)(mM >> 1) & 1u;     // init of branch 0's path (PATH(1, site)->init)
+  const uint32_t root_state = (uint32_t)(mM.w[0] >> 1) & 1u;     // init of branch 0's path (PATH(1, site)->init)
 
   P2_MARK(0);
   bool pending = valid;
@@ -186,7 +244,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     {
       uint32_t gb = 0u;
       for (uint32_t g = 0; g < depth; ++g) {
-        const uint32_t cnt = run ? (uint32_t)__popcll(mH & group_mask(g)) : 0u;
+        const uint32_t cnt = run ? p3_count(mH, group_mask(g)) : 0u;
         const uint32_t incl = wave_incl_scan_u32(cnt);
         s_goff[g * 64u + lane] = (uint16_t)(gb + incl - cnt);
         if (lane == 0) s_gstart[g] = gb;
@@ -198,9 +256,8 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     __builtin_amdgcn_wave_barrier();
     // slot of this lane's heavy pair at `node` in the pair list (and in s_pf / s_pb)
     auto slot_of = [&](uint32_t node) __attribute__((always_inline)) -> uint32_t {
-      const uint32_t nw = s_tree[node];
-      const uint32_t g = EPV_P3_LEAF(nw) ? 0u : EPV_P3_DEPTH(nw);
-      return (uint32_t)s_goff[g * 64u + lane] + (uint32_t)__popcll(mH & group_mask(g) & ((1ull << node) - 1ull));
+      const uint32_t g = EPV_P3_LEAF(s_tree[node]) ? 0u : s_dep[node];
+      return (uint32_t)s_goff[g * 64u + lane] + p3_count_below(mH, group_mask(g), node);
     };
 
     P2_MARK(1);
@@ -208,13 +265,15 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     //         words (the segment counts) share a round trip
     if (run && n_pairs) {
       const uint64_t mbaseL = ((selbits & 1u) ? Bn : 0ull) + (site - 1), mbaseR = ((selbits & 4u) ? Bn : 0ull) + (site + 1);
-      unsigned long long h = mH;
       uint32_t hcur = hbase;
+#pragma unroll
+      for (int hw = 0; hw < W; ++hw) {
+      unsigned long long h = mH.w[hw];
       while (h) {
         uint32_t nd[4], K[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          nd[q] = h ? (uint32_t)(__ffsll((long long)h) - 1) : 0u;
+          nd[q] = h ? 64u * (uint32_t)hw + (uint32_t)(__ffsll((long long)h) - 1) : 0u;
           if (h) h &= h - 1ull;
         }
 #pragma unroll
@@ -225,11 +284,12 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (!nd[q]) continue;
-          const uint32_t leaf_state = (uint32_t)((mM ^ mMp) >> nd[q]) & 1u;
-          plist[slot_of(nd[q])] = (unsigned long long)lane | ((unsigned long long)nd[q] << 6) | ((unsigned long long)K[q] << 12) |
+          const uint32_t leaf_state = p3_get(mM, nd[q]) ^ p3_get(mMp, nd[q]);
+          plist[slot_of(nd[q])] = (unsigned long long)lane | ((unsigned long long)nd[q] << 6) | ((unsigned long long)K[q] << 13) |
                         ((unsigned long long)hcur << 32) | ((unsigned long long)leaf_state << 62);
           hcur += K[q];
         }
+      }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -251,7 +311,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
       uint32_t cL[NP], cR[NP];
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
-        const uint32_t owner = (uint32_t)pr[q] & 63u, b = ((((uint32_t)pr[q] >> 6) & 63u) - 1u) & 63u;
+        const uint32_t owner = (uint32_t)pr[q] & 63u, b = (EPV_P3_PAIR_NODE(pr[q]) - 1u) & 127u;
         const uint32_t osel = (uint32_t)__shfl((int)selbits, (int)owner);
         const uint64_t osite = site_lane0 + 3u * (uint64_t)owner;
         const uint64_t ml = ((osel & 1u) ? Bn : 0ull) + (osite - 1), mr = ((osel & 4u) ? Bn : 0ull) + (osite + 1);
@@ -271,7 +331,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         if (!act[q]) continue;
-        const uint32_t owner = (uint32_t)pr[q] & 63u, node = ((uint32_t)pr[q] >> 6) & 63u, hcur = (uint32_t)(pr[q] >> 32) & 0xfffffu;
+        const uint32_t owner = (uint32_t)pr[q] & 63u, node = EPV_P3_PAIR_NODE(pr[q]), hcur = (uint32_t)(pr[q] >> 32) & 0xfffffu;
         const uint32_t nL = cL[q] & EPV_NJ_MASK, nR = cR[q] & EPV_NJ_MASK, K = nL + nR + 1u;
         uint32_t trip0 = 4u * (cL[q] >> EPV_INIT_SHIFT) + (cR[q] >> EPV_INIT_SHIFT), i = 0, j = 0;
         double seg_start = 0.0;
@@ -332,7 +392,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
         const uint32_t pidx = p0 + (uint32_t)lane;
         if (pidx >= pend) continue;
         const unsigned long long pr = plist[pidx];
-        const uint32_t owner = (uint32_t)pr & 63u, node = ((uint32_t)pr >> 6) & 63u, K = ((uint32_t)(pr >> 12)) & 0xfffffu;
+        const uint32_t owner = (uint32_t)pr & 63u, node = EPV_P3_PAIR_NODE(pr), K = EPV_P3_PAIR_K(pr);
         const uint32_t hrec0 = (uint32_t)(pr >> 32) & 0xfffffu;
         const uint32_t nw = s_tree[node];
         double q0, q1;
@@ -434,7 +494,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     };
     // q of a leaf: the observed state (the end state of the site's current path)
     auto leaf_q = [&](uint32_t node, double &q0, double &q1) __attribute__((always_inline)) {
-      const uint32_t leaf_state = (uint32_t)((mM ^ mMp) >> node) & 1u;
+      const uint32_t leaf_state = p3_get(mM, node) ^ p3_get(mMp, node);
       q0 = leaf_state ? 0.0 : 1.0;
       q1 = leaf_state ? 1.0 : 0.0;
     };
@@ -460,7 +520,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
                 const uint32_t c = w ? EPV_P3_CHILD2(nw) : EPV_P3_CHILD1(nw);
                 if (c == 0u) continue;
                 const uint32_t cw = s_tree[c];
-                if (!EPV_P3_LEAF(cw) && !((mH >> c) & 1ull)) {
+                if (!EPV_P3_LEAF(cw) && !p3_get(mH, c)) {
                   const double *qr = qrows + (size_t)EPV_P3_QROW(cw) * 128u + (size_t)lane * 2u;
                   cq[j][w][0] = qr[0]; cq[j][w][1] = qr[1];
                 }
@@ -478,14 +538,14 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
               const uint32_t c = w ? EPV_P3_CHILD2(nw) : EPV_P3_CHILD1(nw);
               if (c == 0u) continue;
               double f0, f1;
-              if ((mH >> c) & 1ull) {
+              if (p3_get(mH, c)) {
                 const uint32_t sl = slot_of(c);
                 f0 = s_pf[2u * sl]; f1 = s_pf[2u * sl + 1u];
               } else {
                 double q0 = j == 0u ? cq[0][w][0] : j == 1u ? cq[1][w][0] : j == 2u ? cq[2][w][0] : cq[3][w][0];
                 double q1 = j == 0u ? cq[0][w][1] : j == 1u ? cq[1][w][1] : j == 2u ? cq[2][w][1] : cq[3][w][1];
                 if (EPV_P3_LEAF(s_tree[c])) leaf_q(c, q0, q1);
-                const uint32_t ctx = (uint32_t)(((mL >> c) & 1ull) << 1) | (uint32_t)((mR >> c) & 1ull);
+                const uint32_t ctx = (p3_get(mL, c) << 1) | p3_get(mR, c);
                 const double *t = s_tab + ((c - 1u) * 4u + ctx) * EPV_SEGTAB_DBL;     // (32-bit index: an LDS address)
                 const double P00 = t[0], P11 = t[1];
                 const double P01 = 1.0 - P00, P10 = 1.0 - P11;
@@ -508,7 +568,8 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
 
     // ---- 5. downward sampling of the segment END STATES (:180-255), level by level from the root;
     //         the jump times are drawn by epv_mh_jumps_kernel for the dirty branches only
-    unsigned long long mEnd = 0ull, mStart = 0ull, dirty = 0ull, multi = 0ull, deep = 0ull;
+    P3Mask<W> mEnd, mStart, dirty, multi, deep;
+    p3_zero(mEnd); p3_zero(mStart); p3_zero(dirty); p3_zero(multi); p3_zero(deep);
     const uint64_t pcW = (uint64_t)S.phase_cap * S.W, tidW = tid * S.W;
     bool ident = true;
     if (run) {
@@ -522,7 +583,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
             if (ib + (uint32_t)j < i1) {
               const uint32_t c = s_dn[ib + j];
               const uint32_t cw = s_tree[c];
-              if (!EPV_P3_LEAF(cw) && !((mH >> c) & 1ull)) {
+              if (!EPV_P3_LEAF(cw) && !p3_get(mH, c)) {
                 const double *qr = qrows + (size_t)EPV_P3_QROW(cw) * 128u + (size_t)lane * 2u;
                 cq[j][0] = qr[0]; cq[j][1] = qr[1];
               }
@@ -536,14 +597,14 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
             const uint32_t node = __builtin_amdgcn_readfirstlane(s_dn[ib + j]), b = node - 1u;
             const uint32_t nw = __builtin_amdgcn_readfirstlane(s_tree[node]);
             const uint32_t par = EPV_P3_PARENT(nw);
-            const uint32_t start_state = (par == 0u) ? root_state : (uint32_t)(mEnd >> par) & 1u;
+            const uint32_t start_state = (par == 0u) ? root_state : p3_get(mEnd, par);
             uint32_t prev;
             bool clean, b_multi = false, b_deep = false;
-            if (!((mH >> node) & 1ull)) {
+            if (!p3_get(mH, node)) {
               double q0 = j == 0u ? cq[0][0] : j == 1u ? cq[1][0] : j == 2u ? cq[2][0] : cq[3][0];
               double q1 = j == 0u ? cq[0][1] : j == 1u ? cq[1][1] : j == 2u ? cq[2][1] : cq[3][1];
               if (EPV_P3_LEAF(nw)) leaf_q(node, q0, q1);
-              const uint32_t ctx = (uint32_t)(((mL >> node) & 1ull) << 1) | (uint32_t)((mR >> node) & 1ull);
+              const uint32_t ctx = (p3_get(mL, node) << 1) | p3_get(mR, node);
               const double *t = s_tab + (b * 4u + ctx) * EPV_SEGTAB_DBL;
               const double P00 = t[0], P11 = t[1];
               const double P01 = 1.0 - P00, P10 = 1.0 - P11;
@@ -562,14 +623,14 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
               clean = (r >> (start_state ? 3u : 1u)) & 1u;
               b_multi = (r >> 4) & 1u; b_deep = (r >> 5) & 1u;
             }
-            mEnd |= (unsigned long long)prev << node;     // proposal end state for the children
-            mStart |= (unsigned long long)start_state << node;
+            p3_or(mEnd, node, prev);     // proposal end state for the children
+            p3_or(mStart, node, start_state);
             // same as the current path?  (no jumps on either, same start state)
-            ident = ident && clean && !((mMj >> node) & 1ull) && ((uint32_t)(mM >> node) & 1u) == start_state;
+            ident = ident && clean && !p3_get(mMj, node) && p3_get(mM, node) == start_state;
             if (!clean) {
-              dirty |= 1ull << b;
-              if (b_multi) multi |= 1ull << b;   // four buckets by segment count
-              if (b_deep) deep |= 1ull << b;
+              p3_or(dirty, b, 1u);
+              if (b_multi) p3_or(multi, b, 1u);   // four buckets by segment count
+              if (b_deep) p3_or(deep, b, 1u);
             }
           }
         }
@@ -580,14 +641,17 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     for (uint32_t p0 = 0; p0 < totP; p0 += 64u) {
       const uint32_t pidx = p0 + (uint32_t)lane;
       const unsigned long long pr = pidx < totP ? plist[pidx] : 0ull;
-      const uint32_t owner = (uint32_t)pr & 63u, node = ((uint32_t)pr >> 6) & 63u;
-      const unsigned long long oEnd = (unsigned long long)__shfl((uint32_t)mEnd, (int)owner) | ((unsigned long long)__shfl((uint32_t)(mEnd >> 32), (int)owner) << 32);
+      const uint32_t owner = (uint32_t)pr & 63u, node = EPV_P3_PAIR_NODE(pr);
+      P3Mask<W> oEnd;
+#pragma unroll
+      for (int q = 0; q < W; ++q)
+        oEnd.w[q] = (unsigned long long)__shfl((uint32_t)mEnd.w[q], (int)owner) | ((unsigned long long)__shfl((uint32_t)(mEnd.w[q] >> 32), (int)owner) << 32);
       const uint32_t oRoot = (uint32_t)__shfl((int)root_state, (int)owner);
       if (pidx < totP) {
-        const uint32_t K = ((uint32_t)(pr >> 12)) & 0xfffffu, hrec0 = (uint32_t)(pr >> 32) & 0xfffffu;
+        const uint32_t K = EPV_P3_PAIR_K(pr), hrec0 = (uint32_t)(pr >> 32) & 0xfffffu;
         const uint32_t nw = s_tree[node];
         const uint32_t par = EPV_P3_PARENT(nw);
-        const uint32_t st = (par == 0u) ? oRoot : (uint32_t)(oEnd >> par) & 1u;
+        const uint32_t st = (par == 0u) ? oRoot : p3_get(oEnd, par);
         const uint32_t r = s_pb[pidx];
         const bool clean = (r >> (st ? 3u : 1u)) & 1u;
         if (!clean) {
@@ -627,8 +691,16 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
       }
     }
     // (a dirty branch of one segment hands the jump kernel all it needs in the task word)
-    epv_flush_tasks(S, counters, dirty, multi, deep, B - 1u, site, lane, my_shard, dirty & ~(mH >> 1), ((selbits >> 1) & 1u) ^ 1u,
-                    mStart >> 1, mEnd >> 1, mL >> 1, mR >> 1);
+    {
+      const P3Mask<W> bH = p3_shr1(mH), bStart = p3_shr1(mStart), bEnd = p3_shr1(mEnd), bL = p3_shr1(mL), bR = p3_shr1(mR);
+#pragma unroll
+      for (int q = 0; q < W; ++q) {     // (a wave-wide operation per word of 64 branches)
+        if (64u * (uint32_t)q >= B) break;
+        const uint32_t b_last = 64u * (uint32_t)q + 63u < B ? 64u * (uint32_t)q + 63u : B - 1u;
+        epv_flush_tasks(S, counters, dirty.w[q], multi.w[q], deep.w[q], b_last, site, lane, my_shard, dirty.w[q] & ~bH.w[q],
+                        ((selbits >> 1) & 1u) ^ 1u, bStart.w[q], bEnd.w[q], bL.w[q], bR.w[q]);
+      }
+    }
     P2_MARK(6);
 
     // ---- 7. hand-over.  A proposal equal to the current path is accepted with probability one and
@@ -639,7 +711,7 @@ __global__ __launch_bounds__(256, EPV_P3_MINBLOCKS) void epv_mh_propose3_kernel(
     if (to_list) {
       for (uint32_t node = 1u; node < N; ++node) {
         const uint32_t par = EPV_P3_PARENT(s_tree[node]);
-        const uint32_t st = (par == 0u) ? root_state : (uint32_t)(mEnd >> par) & 1u;
+        const uint32_t st = (par == 0u) ? root_state : p3_get(mEnd, par);
         S.meta[((selbits & 2u) ? 0ull : Bn) + (uint64_t)(node - 1u) * n + site] = (epv_meta_t)(st << EPV_INIT_SHIFT);
       }
       S.prop_flag[tid] = 0u;

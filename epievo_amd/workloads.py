@@ -58,6 +58,8 @@ def config(name):
         return host.Tree.balanced(8, 0.05)
     if name == "bal32":          # 63 nodes: the widest tree the large-tree kernels take (node masks are one word)
         return host.Tree.balanced(32, 0.03)
+    if name == "bal64":          # 127 nodes: two words per node mask in the large-tree kernels
+        return host.Tree.balanced(64, 0.02)
     if name == "cat20":          # a caterpillar of 20 leaves: 39 nodes, 19 levels
         text = "(L0:0.05,L1:0.07)I0:0.03"
         for i in range(2, 20):

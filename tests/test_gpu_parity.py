@@ -262,7 +262,8 @@ _SEPARATE = {"EPV_FUSED_PHASE": "0"}      # small launches take the fused phase 
                                        ("bal16", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
                                        ("bal16", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="1", EPV_P3_MIN_LIST="1")),
                                        ("bal16", 9000, dict(_SEPARATE, EPV_P3_SLAB_POOL="2")),
-                                       ("bal32", 1500, dict(_SEPARATE, EPV_PROPOSE_V3="1")), ("cat20", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
+                                       ("bal32", 1500, dict(_SEPARATE, EPV_PROPOSE_V3="1")), ("bal64", 1200, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
+                                       ("bal64", 1200, dict(_SEPARATE, EPV_PROPOSE_V3="1", EPV_P3_MIN_LIST="1", EPV_P3_SLAB_POOL="2")), ("cat20", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
                                        ("cat20", 2000, dict(_SEPARATE, EPV_PROPOSE_V3="1", EPV_P3_MIN_LIST="1", EPV_P3_SLAB_POOL="2")),
                                        ("tree", 20011, dict(_SEPARATE, EPV_PROPOSE_V3="1")),
                                        ("bal16", 2000, dict(_SEPARATE, EPV_ACCEPT_V3="0")),
